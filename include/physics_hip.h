@@ -1,0 +1,182 @@
+/* physics_hip.h — C ABI of libphysics_hip.so, the MI355X (gfx950) backend for the per-frame
+ * rigid-body step of martingoe/physics.
+ *
+ * The reference has no FFI of its own; the surface replaced is the inherent-method surface of
+ * `PhysicsState` (reference src/physics.rs:40-100) and `RigidBody` (src/physics/rigid_body.rs).
+ * Each entry point cites the reference item it stands in for. A Rust shim (rust/physics_hip_sys,
+ * shown in INTEGRATION.md) binds exactly these symbols.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no exceptions cross the boundary.
+ *   - every call returns int32_t: 0 = PHYS_OK, < 0 = error; phys_last_error() gives the text
+ *     (thread-local). The reference panics instead (unwrap at rigid_body.rs:31, assert_eq at
+ *     sparse_matrix.rs:26,40); a panic cannot cross FFI, so the same conditions become codes.
+ *   - a phys_world* is used from one thread at a time (mirrors `&mut self`).
+ *   - host arrays passed in are copied before the call returns; output arrays are caller-allocated.
+ *   - quaternions are [i, j, k, w] (nalgebra storage order), matrices row-major unless stated.
+ *   - there is NO CPU fallback: phys_create fails with PHYS_ERR_NO_DEVICE when no gfx950 device
+ *     is usable.
+ */
+#ifndef PHYSICS_HIP_H
+#define PHYSICS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PHYS_ABI_VERSION 1u
+
+/* status codes */
+#define PHYS_OK 0
+#define PHYS_ERR_INVALID_ARG (-1)
+#define PHYS_ERR_NO_DEVICE (-2)
+#define PHYS_ERR_HIP (-3)
+#define PHYS_ERR_SINGULAR_INERTIA (-4) /* reference: try_inverse().unwrap() panic, rigid_body.rs:31 */
+#define PHYS_ERR_CAPACITY (-5)         /* pair / manifold buffer overflow (sticky until reset) */
+#define PHYS_ERR_OUT_OF_RANGE (-6)     /* body index out of range (reference: Vec index panic) */
+#define PHYS_ERR_UNSUPPORTED (-7)
+#define PHYS_ERR_NO_BODIES (-8)        /* reference: view() panic on N = 0 */
+
+/* shape types (new: the reference has no shapes) */
+#define PHYS_SHAPE_NONE 0u   /* takes part in integration only */
+#define PHYS_SHAPE_SPHERE 1u /* radius = half_extent[0] */
+#define PHYS_SHAPE_BOX 2u    /* half extents along the body axes */
+
+/* phys_config.flags */
+#define PHYS_FLAG_COLLISIONS 0x1u     /* run broad-phase + narrow-phase + sequential impulses */
+#define PHYS_FLAG_GROUND_PLANE 0x2u   /* static plane y = ground_height, normal +y */
+#define PHYS_FLAG_EXACT_ROTATION 0x4u /* OFF (default) = reference quirk Q1: dq = exp(a*sin(th/2)/2) */
+#define PHYS_FLAG_BROADPHASE_ONLY 0x8u /* with COLLISIONS: stop after the candidate-pair list */
+
+typedef struct phys_config {
+    uint32_t abi_version;       /* PHYS_ABI_VERSION */
+    int32_t device;             /* HIP device ordinal */
+    uint32_t flags;             /* default 0: pure reference semantics (no collisions) */
+    float gravity_force[3];     /* default (0,-9.81,0): a FORCE, not m*g (physics.rs:90, quirk Q2) */
+    float gravity_offset[3];    /* default (0,0,1.5) world offset (physics.rs:91, quirk Q2) */
+    uint32_t cg_max_iterations; /* default 1000 (sle_solver.rs:5) */
+    float cg_max_error;         /* default 1e-2 (sle_solver.rs:6) */
+    float cg_min_error;         /* default 1e-3 (sle_solver.rs:7) */
+    uint32_t solver_iterations; /* sequential-impulse iterations, default 8 */
+    float baumgarte;            /* default 0.2 */
+    float slop;                 /* penetration allowance, default 0.01 */
+    float friction;             /* Coulomb coefficient, default 0.5 */
+    float contact_margin;       /* AABB fattening / speculative distance, default 0.02 */
+    float ground_height;        /* default 0 */
+    float max_bias;             /* cap on the contact push-out velocity, default 3.0 */
+    uint64_t max_pairs;         /* 0 = auto (24 per body) */
+    uint64_t max_manifolds;     /* 0 = auto (16 per body) */
+} phys_config;
+
+typedef struct phys_world phys_world;
+
+typedef struct phys_stats {
+    uint64_t n_bodies;
+    uint64_t n_pairs;      /* candidate pairs of the last update */
+    uint64_t n_manifolds;  /* body-body + body-ground manifolds */
+    uint64_t n_contacts;   /* contact points */
+    uint32_t n_colors;     /* solver colours */
+    uint32_t color_rounds; /* colouring rounds */
+    uint32_t cg_iterations; /* CG iterations of the last constraint solve */
+    int32_t cg_converged;   /* 1 = Some(lambda), 0 = None (sle_solver.rs:45) */
+    uint64_t steps;         /* updates since creation */
+    uint32_t overflow;      /* sticky capacity overflow flags */
+    uint32_t reserved;
+} phys_stats;
+
+/* reference defaults (see phys_config field comments) */
+void phys_config_default(phys_config* cfg);
+const char* phys_last_error(void);
+uint32_t phys_abi_version(void);
+
+/* PhysicsState { .. } literal at lib.rs:34-42 / drop */
+int32_t phys_create(const phys_config* cfg, phys_world** out);
+int32_t phys_destroy(phys_world* w);
+
+/* entities: Vec<Entity> (physics.rs:26). One call replaces the whole body set.
+ * Any pointer except pos may be NULL -> RigidBody::new defaults (rigid_body.rs:64-76):
+ * rot identity, velocities 0, mass 1, inertia identity, shape NONE. */
+int32_t phys_set_bodies(phys_world* w, uint64_t n, const float* pos /*3n*/, const float* rot_ijkw /*4n*/,
+                        const float* lin_vel /*3n*/, const float* ang_vel /*3n*/, const float* mass /*n*/,
+                        const float* inertia /*9n row-major*/, const uint32_t* shape_type /*n*/,
+                        const float* half_extent /*3n*/);
+
+/* ConstraintSolver.constraints.push(Constraints::FixedPosition(..)) (lib.rs:24, fixed_position_constraint.rs) */
+int32_t phys_add_constraint_fix_point(phys_world* w, uint64_t body, const float target[3]);
+/* Constraints::FixedOrientation (lib.rs:25, fixed_orientation_constraint.rs); target = (roll,pitch,yaw) */
+int32_t phys_add_constraint_fix_orientation(phys_world* w, uint64_t body, const float target_rpy[3]);
+int32_t phys_clear_constraints(phys_world* w);
+
+/* RigidBody::apply_force_centre_of_gravity / apply_force_at_position / apply_force_at_offset
+ * (rigid_body.rs:43-62) */
+int32_t phys_apply_force_centre_of_gravity(phys_world* w, uint64_t body, const float force[3]);
+int32_t phys_apply_force_at_position(phys_world* w, uint64_t body, const float force[3], const float point[3]);
+int32_t phys_apply_force_at_offset(phys_world* w, uint64_t body, const float force[3], const float offset[3]);
+
+/* PhysicsState::update(&mut self, dt: &Duration) (physics.rs:41-55). dt is passed as whole
+ * nanoseconds so Duration::as_secs_f32 (rigid_body.rs:25) is reproduced bit for bit. */
+int32_t phys_update(phys_world* w, uint64_t dt_nanos);
+/* PhysicsState::apply_gravity (physics.rs:87-94) */
+int32_t phys_apply_gravity(phys_world* w);
+/* PhysicsState::step(&mut self, dt) (physics.rs:95-99) = RigidBody::step for every body */
+int32_t phys_step(phys_world* w, uint64_t dt_nanos);
+/* n updates back to back without returning to the host in between (same result as n phys_update) */
+int32_t phys_update_n(phys_world* w, uint64_t dt_nanos, uint32_t n);
+/* block until all queued device work of this world is done; reports sticky device-side errors */
+int32_t phys_sync(phys_world* w);
+
+/* body.position / body.rotation reads (physics.rs:64-65); synchronous device-to-host */
+int32_t phys_get_transforms(phys_world* w, float* pos_out /*3n*/, float* rot_ijkw_out /*4n*/);
+/* body.lin_velocity / body.angular_velocity (pub fields, rigid_body.rs:9-10) */
+int32_t phys_get_velocities(phys_world* w, float* lin_out /*3n*/, float* ang_out /*3n*/);
+/* body.force / body.torque accumulators (pub(crate), rigid_body.rs:12-13) */
+int32_t phys_get_forces(phys_world* w, float* force_out /*3n*/, float* torque_out /*3n*/);
+/* Instance::to_raw for every entity (graphics.rs:13-21; consumed at physics.rs:61-69):
+ * 16 f32 per body, column-major T(position) * R(rotation) */
+int32_t phys_get_instance_matrices(phys_world* w, float* out /*16n*/);
+/* previous_solution (physics.rs:30): warm-start lambda; *n_rows = 0 when None */
+int32_t phys_get_lambda(phys_world* w, float* lambda_out, uint64_t cap, uint64_t* n_rows);
+
+/* broad-phase of the current poses: candidate pairs (i < j) with overlapping fattened AABBs,
+ * sorted by (i, j). pairs_out may be NULL to query the count. (new: SURVEY §8 A10) */
+int32_t phys_broadphase(phys_world* w, uint32_t* pairs_out /*2*cap*/, uint64_t cap, uint64_t* n_pairs);
+/* AABBs as computed by the device: min xyz, max xyz per body */
+int32_t phys_get_aabbs(phys_world* w, float* out /*6n*/);
+/* contact manifolds of the last update, sorted by (body_a, body_b); body_b = 0xFFFFFFFF = ground.
+ * rows: per manifold 2 u32 ids + u32 count; per point (4 slots): position xyz + depth. NULLs allowed. */
+int32_t phys_get_manifolds(phys_world* w, uint32_t* ids_out /*2*cap*/, uint32_t* counts_out /*cap*/,
+                           float* normals_out /*3*cap*/, float* points_out /*16*cap*/, uint64_t cap,
+                           uint64_t* n_manifolds);
+int32_t phys_get_stats(phys_world* w, phys_stats* out);
+
+/* --- device-side access for zero-copy callers (torch / RCCL plumbing) and multi-GPU halos --- */
+typedef struct phys_device_view {
+    uint64_t n;
+    float* pos;     /* 3n */
+    float* rot;     /* 4n */
+    float* lin_vel; /* 3n */
+    float* ang_vel; /* 3n */
+    float* aabb;    /* 6n: min xyz max xyz, valid after an update with COLLISIONS or phys_broadphase */
+    void* stream;   /* hipStream_t the world launches on */
+} phys_device_view;
+int32_t phys_get_device_view(phys_world* w, phys_device_view* out);
+
+/* Sharded broad-phase. Each rank owns the bodies it was given; a halo record is
+ * 32 B: {min xyz, max xyz, global id, pad}. phys_halo_pack writes to DEVICE memory the records of
+ * owned bodies whose fattened AABB reaches outside [x_lo + reach, x_hi - reach] (reach = one grid
+ * cell), returns the count. phys_halo_pairs takes the gathered records of the OTHER ranks (device
+ * memory) and appends owned-vs-remote candidate pairs (local index, global id of the remote body)
+ * under the ownership rule "emitted by the rank owning the body with the smaller global id". */
+int32_t phys_set_global_ids(phys_world* w, const uint32_t* global_ids /*n*/);
+int32_t phys_halo_pack(phys_world* w, float x_lo, float x_hi, void* dev_records_out, uint64_t cap,
+                       uint64_t* n_records);
+int32_t phys_halo_pairs(phys_world* w, const void* dev_remote_records, uint64_t n_remote,
+                        uint64_t* n_cross_pairs);
+int32_t phys_get_cross_pairs(phys_world* w, uint32_t* pairs_out /*2*cap*/, uint64_t cap, uint64_t* n_pairs);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PHYSICS_HIP_H */

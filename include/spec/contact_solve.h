@@ -1,0 +1,157 @@
+/* contact_solve.h — normative scalar definition of the sequential-impulse contact solver
+ *  and of the deterministic manifold colouring that orders it.
+ *
+ * No reference counterpart exists ("parity unpinned"): the reference's solver is the global CG
+ * of constraints.rs / sle_solver.rs, which stays in scope separately. This header is the
+ * specification; HIP kernels and the CPU oracle both compile it (see collide.h header).
+ *
+ * Solver order (what makes a parallel run equal a sequential one):
+ *   for iteration in 0..solver_iterations:
+ *     for colour in 0..n_colours (ascending):
+ *       every manifold of that colour, in any order (they share no body)
+ *   inside a manifold: points in index order; per point tangent 1, tangent 2, then normal.
+ *
+ * Colouring (Jones-Plassmann on the line graph, synchronous rounds; a pure function of the SET of
+ * manifolds, independent of their storage order):
+ *   priority(m) = mix64(a << 32 | b)           (bijective, so priorities are distinct)
+ *   round: top[body] = max priority over that body's uncoloured manifolds;
+ *          an uncoloured manifold that is top at every dynamic body it touches takes the lowest
+ *          colour not yet used at those bodies, and marks it used there.
+ *   repeat until all are coloured. At most PHYS_MAX_COLORS colours.
+ */
+#ifndef PHYS_SPEC_CONTACT_SOLVE_H
+#define PHYS_SPEC_CONTACT_SOLVE_H
+
+#include "collide.h"
+
+#define PHYS_MAX_COLORS 64
+
+typedef struct {
+    float dt;
+    float baumgarte;
+    float slop;
+    float friction;
+    float max_bias; /* cap on the push-out velocity */
+} solve_params_t;
+
+typedef struct {
+    v3 rA, rB;
+    float normal_mass;
+    float tangent_mass[2];
+    float bias;
+    float pn;
+    float pt[2];
+} contact_row_t;
+
+typedef struct {
+    v3 n, t1, t2;
+    int count;
+    int has_b; /* 0: body B is the static ground */
+    contact_row_t row[4];
+} solver_manifold_t;
+
+PHYS_HD uint64_t color_priority(uint32_t a, uint32_t b) {
+    uint64_t z = ((uint64_t)a << 32) | (uint64_t)b;
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+/* orthonormal tangents of a unit normal */
+PHYS_HD void tangent_basis(v3 n, v3* t1, v3* t2) {
+    v3 t;
+    if (det_absf(n.x) >= 0.57735f) t = v3_make(n.y, -n.x, 0.0f);
+    else                           t = v3_make(0.0f, n.z, -n.y);
+    t = v3_div(t, v3_norm(t));
+    *t1 = t;
+    *t2 = v3_cross(n, t);
+}
+
+PHYS_HD float direction_mass(v3 dir, v3 rA, v3 rB, float invMA, const m33* IA, float invMB, const m33* IB, int has_b) {
+    const v3 ra = v3_cross(rA, dir);
+    float k = invMA + v3_dot(m33_mul_v3(IA, ra), ra);
+    if (has_b) {
+        const v3 rb = v3_cross(rB, dir);
+        k = (k + invMB) + v3_dot(m33_mul_v3(IB, rb), rb);
+    }
+    return k > 0.0f ? 1.0f / k : 0.0f;
+}
+
+/* build the solver rows of one manifold. xB / invMB / IB are ignored when has_b == 0. */
+PHYS_HD void solver_prep(const manifold_t* m, int has_b, v3 xA, v3 xB, float invMA, const m33* IA, float invMB,
+                         const m33* IB, const solve_params_t* sp, solver_manifold_t* out) {
+    out->n = m->normal;
+    tangent_basis(m->normal, &out->t1, &out->t2);
+    out->count = m->count;
+    out->has_b = has_b;
+    for (int k = 0; k < 4; ++k) {
+        contact_row_t* r = &out->row[k];
+        if (k < m->count) {
+            r->rA = v3_sub(m->pt[k], xA);
+            r->rB = has_b ? v3_sub(m->pt[k], xB) : v3_make(0.0f, 0.0f, 0.0f);
+            r->normal_mass = direction_mass(out->n, r->rA, r->rB, invMA, IA, invMB, IB, has_b);
+            r->tangent_mass[0] = direction_mass(out->t1, r->rA, r->rB, invMA, IA, invMB, IB, has_b);
+            r->tangent_mass[1] = direction_mass(out->t2, r->rA, r->rB, invMA, IA, invMB, IB, has_b);
+            const float depth = m->depth[k];
+            float bias = 0.0f;
+            if (depth > sp->slop) bias = det_minf((sp->baumgarte / sp->dt) * (depth - sp->slop), sp->max_bias);
+            else if (depth < 0.0f) bias = depth / sp->dt; /* speculative: may close the gap, not more */
+            r->bias = bias;
+        } else {
+            r->rA = v3_make(0.0f, 0.0f, 0.0f);
+            r->rB = v3_make(0.0f, 0.0f, 0.0f);
+            r->normal_mass = 0.0f; r->tangent_mass[0] = 0.0f; r->tangent_mass[1] = 0.0f; r->bias = 0.0f;
+        }
+        r->pn = 0.0f; r->pt[0] = 0.0f; r->pt[1] = 0.0f;
+    }
+}
+
+PHYS_HD void apply_impulse(v3 P, v3 rA, v3 rB, float invMA, const m33* IA, float invMB, const m33* IB, int has_b,
+                           v3* vA, v3* wA, v3* vB, v3* wB) {
+    *vA = v3_sub(*vA, v3_scale(P, invMA));
+    *wA = v3_sub(*wA, m33_mul_v3(IA, v3_cross(rA, P)));
+    if (has_b) {
+        *vB = v3_add(*vB, v3_scale(P, invMB));
+        *wB = v3_add(*wB, m33_mul_v3(IB, v3_cross(rB, P)));
+    }
+}
+
+PHYS_HD v3 relative_velocity(v3 rA, v3 rB, int has_b, v3 vA, v3 wA, v3 vB, v3 wB) {
+    const v3 pa = v3_add(vA, v3_cross(wA, rA));
+    if (!has_b) return v3_neg(pa);
+    const v3 pb = v3_add(vB, v3_cross(wB, rB));
+    return v3_sub(pb, pa);
+}
+
+/* one Gauss-Seidel sweep over the points of one manifold; velocities are updated in place */
+PHYS_HD void solve_manifold(solver_manifold_t* sm, float friction, float invMA, const m33* IA, float invMB,
+                            const m33* IB, v3* vA, v3* wA, v3* vB, v3* wB) {
+    const int has_b = sm->has_b;
+    for (int k = 0; k < 4; ++k) {
+        if (k >= sm->count) break;
+        contact_row_t* r = &sm->row[k];
+        for (int t = 0; t < 2; ++t) {
+            const v3 dir = t == 0 ? sm->t1 : sm->t2;
+            const v3 dv = relative_velocity(r->rA, r->rB, has_b, *vA, *wA, *vB, *wB);
+            float lambda = -r->tangent_mass[t] * v3_dot(dv, dir);
+            const float maxf = friction * r->pn;
+            const float old = r->pt[t];
+            const float np = det_maxf(-maxf, det_minf(old + lambda, maxf));
+            lambda = np - old;
+            r->pt[t] = np;
+            apply_impulse(v3_scale(dir, lambda), r->rA, r->rB, invMA, IA, invMB, IB, has_b, vA, wA, vB, wB);
+        }
+        {
+            const v3 dv = relative_velocity(r->rA, r->rB, has_b, *vA, *wA, *vB, *wB);
+            float lambda = r->normal_mass * (r->bias - v3_dot(dv, sm->n));
+            const float old = r->pn;
+            const float np = det_maxf(old + lambda, 0.0f);
+            lambda = np - old;
+            r->pn = np;
+            apply_impulse(v3_scale(sm->n, lambda), r->rA, r->rB, invMA, IA, invMB, IB, has_b, vA, wA, vB, wB);
+        }
+    }
+}
+
+#endif /* PHYS_SPEC_CONTACT_SOLVE_H */

@@ -1,0 +1,250 @@
+// collide_oracle.cpp — CPU ORACLE (test infrastructure, NOT product code). See collide_oracle.hpp.
+#include "collide_oracle.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <numeric>
+
+namespace oracle {
+
+void CollisionWorld::configure(const phys_config& cfg) {
+    flags = cfg.flags;
+    margin = cfg.contact_margin;
+    ground = cfg.ground_height;
+    iterations = cfg.solver_iterations;
+    sp.dt = 0.0f;
+    sp.baumgarte = cfg.baumgarte;
+    sp.slop = cfg.slop;
+    sp.friction = cfg.friction;
+    sp.max_bias = cfg.max_bias;
+}
+
+static inline v3 V(const float* p) { return v3_make(p[0], p[1], p[2]); }
+static inline quat Q(const float* p) { quat q; q.i = p[0]; q.j = p[1]; q.k = p[2]; q.w = p[3]; return q; }
+
+void CollisionWorld::compute_aabbs(const std::vector<RigidBody>& bodies) {
+    const size_t n = bodies.size();
+    aabb.resize(6 * n);
+    for (size_t i = 0; i < n; ++i) {
+        const aabb_t b = body_aabb(V(bodies[i].position), Q(bodies[i].rotation), V(&half_extent[3 * i]), shape_type[i], margin);
+        aabb[6 * i + 0] = b.lo.x; aabb[6 * i + 1] = b.lo.y; aabb[6 * i + 2] = b.lo.z;
+        aabb[6 * i + 3] = b.hi.x; aabb[6 * i + 4] = b.hi.y; aabb[6 * i + 5] = b.hi.z;
+    }
+}
+
+static inline aabb_t box_at(const std::vector<float>& aabb, size_t i) {
+    aabb_t b;
+    b.lo = v3_make(aabb[6 * i], aabb[6 * i + 1], aabb[6 * i + 2]);
+    b.hi = v3_make(aabb[6 * i + 3], aabb[6 * i + 4], aabb[6 * i + 5]);
+    return b;
+}
+
+void CollisionWorld::broadphase_sweep() {
+    const size_t n = aabb.size() / 6;
+    pairs.clear();
+    std::vector<uint32_t> order;
+    for (size_t i = 0; i < n; ++i)
+        if (shape_type[i] != PHYS_SHAPE_NONE) order.push_back((uint32_t)i);
+    std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
+        const float lx = aabb[6 * x], ly = aabb[6 * y];
+        return lx < ly || (lx == ly && x < y);
+    });
+    for (size_t s = 0; s < order.size(); ++s) {
+        const uint32_t i = order[s];
+        const aabb_t bi = box_at(aabb, i);
+        for (size_t t = s + 1; t < order.size(); ++t) {
+            const uint32_t j = order[t];
+            if (aabb[6 * j] > bi.hi.x) break;
+            if (aabb_overlap(bi, box_at(aabb, j))) pairs.emplace_back(std::min(i, j), std::max(i, j));
+        }
+    }
+    std::sort(pairs.begin(), pairs.end());
+}
+
+void CollisionWorld::broadphase_grid() {
+    const size_t n = aabb.size() / 6;
+    pairs.clear();
+    // cell = largest AABB extent: overlapping boxes then have centres in adjacent cells
+    float cell = 0.0f;
+    std::vector<uint32_t> ids;
+    for (size_t i = 0; i < n; ++i) {
+        if (shape_type[i] == PHYS_SHAPE_NONE) continue;
+        ids.push_back((uint32_t)i);
+        for (int k = 0; k < 3; ++k) cell = std::max(cell, aabb[6 * i + 3 + k] - aabb[6 * i + k]);
+    }
+    if (ids.empty()) return;
+    if (!(cell > 0.0f)) cell = 1.0f;
+    const double inv = 1.0 / (double)cell;
+    auto cell_of = [&](uint32_t i, int k) -> int64_t {
+        const double c = 0.5 * ((double)aabb[6 * i + k] + (double)aabb[6 * i + 3 + k]);
+        return (int64_t)std::floor(c * inv);
+    };
+    auto key_of = [](int64_t x, int64_t y, int64_t z) -> uint64_t {
+        const uint64_t B = 1ull << 20;
+        return ((uint64_t)(x + (int64_t)B) << 42) | ((uint64_t)(y + (int64_t)B) << 21) | (uint64_t)(z + (int64_t)B);
+    };
+    std::vector<std::pair<uint64_t, uint32_t>> keyed;
+    keyed.reserve(ids.size());
+    for (uint32_t i : ids) keyed.emplace_back(key_of(cell_of(i, 0), cell_of(i, 1), cell_of(i, 2)), i);
+    std::sort(keyed.begin(), keyed.end());
+    for (uint32_t i : ids) {
+        const int64_t cx = cell_of(i, 0), cy = cell_of(i, 1), cz = cell_of(i, 2);
+        const aabb_t bi = box_at(aabb, i);
+        for (int64_t dx = -1; dx <= 1; ++dx)
+            for (int64_t dy = -1; dy <= 1; ++dy)
+                for (int64_t dz = -1; dz <= 1; ++dz) {
+                    const uint64_t key = key_of(cx + dx, cy + dy, cz + dz);
+                    auto it = std::lower_bound(keyed.begin(), keyed.end(), std::make_pair(key, (uint32_t)0));
+                    for (; it != keyed.end() && it->first == key; ++it) {
+                        const uint32_t j = it->second;
+                        if (j > i && aabb_overlap(bi, box_at(aabb, j))) pairs.emplace_back(i, j);
+                    }
+                }
+    }
+    std::sort(pairs.begin(), pairs.end());
+}
+
+static inline geom_t geom_of(const RigidBody& b, const float* h, uint32_t type) {
+    return geom_make(V(b.position), Q(b.rotation), V(h), type);
+}
+
+void CollisionWorld::narrowphase(const std::vector<RigidBody>& bodies) {
+    manifolds.clear();
+    n_contacts = 0;
+    for (const auto& pr : pairs) {
+        const uint32_t a = pr.first, b = pr.second;
+        const geom_t ga = geom_of(bodies[a], &half_extent[3 * a], shape_type[a]);
+        const geom_t gb = geom_of(bodies[b], &half_extent[3 * b], shape_type[b]);
+        manifold_t m;
+        collide_pair(&ga, &gb, margin, &m);
+        if (m.count > 0) {
+            Manifold M{a, b, m.normal, m.count, {m.pt[0], m.pt[1], m.pt[2], m.pt[3]}, {m.depth[0], m.depth[1], m.depth[2], m.depth[3]}};
+            manifolds.push_back(M);
+            n_contacts += (uint64_t)m.count;
+        }
+    }
+    if (flags & PHYS_FLAG_GROUND_PLANE) {
+        for (size_t i = 0; i < bodies.size(); ++i) {
+            if (shape_type[i] == PHYS_SHAPE_NONE) continue;
+            const geom_t ga = geom_of(bodies[i], &half_extent[3 * i], shape_type[i]);
+            manifold_t m;
+            collide_ground(&ga, ground, margin, &m);
+            if (m.count > 0) {
+                Manifold M{(uint32_t)i, PHYS_GROUND_ID, m.normal, m.count, {m.pt[0], m.pt[1], m.pt[2], m.pt[3]}, {m.depth[0], m.depth[1], m.depth[2], m.depth[3]}};
+                manifolds.push_back(M);
+                n_contacts += (uint64_t)m.count;
+            }
+        }
+    }
+}
+
+void CollisionWorld::color_manifolds(size_t n_bodies) {
+    const size_t M = manifolds.size();
+    const uint32_t UNCOLORED = 0xFFFFFFFFu;
+    color.assign(M, UNCOLORED);
+    std::vector<uint64_t> used(n_bodies, 0ull), top(n_bodies, 0ull), prio(M);
+    for (size_t m = 0; m < M; ++m) prio[m] = color_priority(manifolds[m].a, manifolds[m].b);
+    size_t remaining = M;
+    n_colors = 0;
+    color_rounds = 0;
+    std::vector<size_t> winners;
+    while (remaining > 0) {
+        std::fill(top.begin(), top.end(), 0ull);
+        for (size_t m = 0; m < M; ++m) {
+            if (color[m] != UNCOLORED) continue;
+            const Manifold& mf = manifolds[m];
+            top[mf.a] = std::max(top[mf.a], prio[m]);
+            if (mf.b != PHYS_GROUND_ID) top[mf.b] = std::max(top[mf.b], prio[m]);
+        }
+        winners.clear();
+        for (size_t m = 0; m < M; ++m) {
+            if (color[m] != UNCOLORED) continue;
+            const Manifold& mf = manifolds[m];
+            if (prio[m] == top[mf.a] && (mf.b == PHYS_GROUND_ID || prio[m] == top[mf.b])) winners.push_back(m);
+        }
+        for (size_t m : winners) {
+            const Manifold& mf = manifolds[m];
+            uint64_t mask = used[mf.a];
+            if (mf.b != PHYS_GROUND_ID) mask |= used[mf.b];
+            uint32_t c = 0;
+            while (c < PHYS_MAX_COLORS - 1 && ((mask >> c) & 1ull)) ++c;
+            color[m] = c;
+            used[mf.a] |= 1ull << c;
+            if (mf.b != PHYS_GROUND_ID) used[mf.b] |= 1ull << c;
+            n_colors = std::max(n_colors, c + 1);
+        }
+        remaining -= winners.size();
+        ++color_rounds;
+    }
+}
+
+void CollisionWorld::solve(std::vector<RigidBody>& bodies, float dt) {
+    const size_t M = manifolds.size();
+    sp.dt = dt;
+    // world-frame inverse inertia, the reference's convention (quirk Q5): constant, never rotated
+    std::vector<m33> inv_inertia(bodies.size());
+    std::vector<float> inv_mass(bodies.size());
+    for (size_t i = 0; i < bodies.size(); ++i) {
+        m33 I;
+        for (int k = 0; k < 9; ++k) I.m[k] = bodies[i].inertia_tensor[k];
+        if (!m33_try_inverse(&I, &inv_inertia[i]))
+            for (int k = 0; k < 9; ++k) inv_inertia[i].m[k] = 0.0f;
+        inv_mass[i] = 1.0f / bodies[i].mass;
+    }
+    std::vector<solver_manifold_t> rows(M);
+    const m33 zero{};
+    for (size_t m = 0; m < M; ++m) {
+        const Manifold& mf = manifolds[m];
+        manifold_t g;
+        g.normal = mf.normal; g.count = mf.count;
+        for (int k = 0; k < 4; ++k) { g.pt[k] = mf.pt[k]; g.depth[k] = mf.depth[k]; }
+        const int has_b = mf.b != PHYS_GROUND_ID;
+        solver_prep(&g, has_b, V(bodies[mf.a].position), has_b ? V(bodies[mf.b].position) : v3_make(0, 0, 0),
+                    inv_mass[mf.a], &inv_inertia[mf.a], has_b ? inv_mass[mf.b] : 0.0f,
+                    has_b ? &inv_inertia[mf.b] : &zero, &sp, &rows[m]);
+    }
+    // colour-major order; inside a colour the order is irrelevant (disjoint bodies)
+    std::vector<std::vector<size_t>> by_color(n_colors);
+    for (size_t m = 0; m < M; ++m) by_color[color[m]].push_back(m);
+    for (uint32_t it = 0; it < iterations; ++it)
+        for (uint32_t c = 0; c < n_colors; ++c)
+            for (size_t m : by_color[c]) {
+                const Manifold& mf = manifolds[m];
+                const int has_b = mf.b != PHYS_GROUND_ID;
+                RigidBody& A = bodies[mf.a];
+                v3 vA = V(A.lin_velocity), wA = V(A.angular_velocity);
+                v3 vB = v3_make(0, 0, 0), wB = v3_make(0, 0, 0);
+                if (has_b) { vB = V(bodies[mf.b].lin_velocity); wB = V(bodies[mf.b].angular_velocity); }
+                solve_manifold(&rows[m], sp.friction, inv_mass[mf.a], &inv_inertia[mf.a], has_b ? inv_mass[mf.b] : 0.0f,
+                               has_b ? &inv_inertia[mf.b] : &zero, &vA, &wA, &vB, &wB);
+                A.lin_velocity[0] = vA.x; A.lin_velocity[1] = vA.y; A.lin_velocity[2] = vA.z;
+                A.angular_velocity[0] = wA.x; A.angular_velocity[1] = wA.y; A.angular_velocity[2] = wA.z;
+                if (has_b) {
+                    RigidBody& B = bodies[mf.b];
+                    B.lin_velocity[0] = vB.x; B.lin_velocity[1] = vB.y; B.lin_velocity[2] = vB.z;
+                    B.angular_velocity[0] = wB.x; B.angular_velocity[1] = wB.y; B.angular_velocity[2] = wB.z;
+                }
+            }
+}
+
+void CollisionWorld::collide_and_solve(std::vector<RigidBody>& bodies, float dt) {
+    compute_aabbs(bodies);
+    broadphase_grid();
+    if (flags & PHYS_FLAG_BROADPHASE_ONLY) { manifolds.clear(); color.clear(); n_colors = 0; n_contacts = 0; return; }
+    narrowphase(bodies);
+    color_manifolds(bodies.size());
+    solve(bodies, dt);
+}
+
+std::vector<size_t> CollisionWorld::sorted_manifold_order() const {
+    std::vector<size_t> order(manifolds.size());
+    std::iota(order.begin(), order.end(), (size_t)0);
+    std::sort(order.begin(), order.end(), [&](size_t x, size_t y) {
+        const Manifold& a = manifolds[x];
+        const Manifold& b = manifolds[y];
+        return a.a < b.a || (a.a == b.a && a.b < b.b);
+    });
+    return order;
+}
+
+}  // namespace oracle

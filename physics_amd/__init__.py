@@ -1,0 +1,10 @@
+"""physics_amd — MI355X (gfx950) backend for the per-frame rigid-body step of martingoe/physics.
+
+Host-side mirror of the reference's `PhysicsState` surface over the C ABI of libphysics_hip.so
+(include/physics_hip.h). The compute path is hand-written HIP; there is no CPU fallback."""
+from ._abi import (FLAG_BROADPHASE_ONLY, FLAG_COLLISIONS, FLAG_EXACT_ROTATION, FLAG_GROUND_PLANE, GROUND_ID,
+                   SHAPE_BOX, SHAPE_NONE, SHAPE_SPHERE, PhysicsHipMissing, default_config)
+from .world import PhysError, World
+
+__all__ = ["World", "PhysError", "PhysicsHipMissing", "default_config", "FLAG_COLLISIONS", "FLAG_GROUND_PLANE",
+           "FLAG_EXACT_ROTATION", "FLAG_BROADPHASE_ONLY", "SHAPE_NONE", "SHAPE_SPHERE", "SHAPE_BOX", "GROUND_ID"]

@@ -1,0 +1,469 @@
+// abi.hip — the extern "C" surface of libphysics_hip.so (include/physics_hip.h). Host code only:
+// argument checking, uploads, and the per-frame launch sequence. All compute is in HIP kernels; there
+// is no CPU fallback anywhere in this library.
+#include <algorithm>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "kernels.hpp"
+
+namespace phys {
+static thread_local std::string g_error;
+void set_error(const std::string& msg) { g_error = msg; }
+const char* get_error() { return g_error.c_str(); }
+}  // namespace phys
+
+using namespace phys;
+
+static int32_t fail(int32_t code, const char* msg) {
+    set_error(msg);
+    return code;
+}
+
+// std::time::Duration::as_secs_f32 (used at rigid_body.rs:25)
+static float duration_as_secs_f32(uint64_t nanos_total) {
+    const uint64_t secs = nanos_total / 1000000000ull;
+    const uint32_t nanos = (uint32_t)(nanos_total % 1000000000ull);
+    return (float)secs + (float)nanos / 1.0e9f;
+}
+
+#define ENTER(w)                                                                    \
+    do {                                                                            \
+        if (!(w)) return fail(PHYS_ERR_INVALID_ARG, "null world");                  \
+        PHYS_HIP_TRY(hipSetDevice((w)->device));                                    \
+    } while (0)
+
+extern "C" {
+
+void phys_config_default(phys_config* cfg) {
+    if (!cfg) return;
+    std::memset(cfg, 0, sizeof(*cfg));
+    cfg->abi_version = PHYS_ABI_VERSION;
+    cfg->device = 0;
+    cfg->flags = 0;
+    cfg->gravity_force[0] = 0.0f; cfg->gravity_force[1] = -9.81f; cfg->gravity_force[2] = 0.0f;  // physics.rs:90
+    cfg->gravity_offset[0] = 0.0f; cfg->gravity_offset[1] = 0.0f; cfg->gravity_offset[2] = 1.5f;  // physics.rs:91
+    cfg->cg_max_iterations = 1000;  // sle_solver.rs:5
+    cfg->cg_max_error = 1e-2f;      // sle_solver.rs:6
+    cfg->cg_min_error = 1e-3f;      // sle_solver.rs:7
+    cfg->solver_iterations = 8;
+    cfg->baumgarte = 0.2f;
+    cfg->slop = 0.01f;
+    cfg->friction = 0.5f;
+    cfg->contact_margin = 0.02f;
+    cfg->ground_height = 0.0f;
+    cfg->max_bias = 3.0f;
+    cfg->max_pairs = 0;
+    cfg->max_manifolds = 0;
+}
+
+const char* phys_last_error(void) { return get_error(); }
+uint32_t phys_abi_version(void) { return PHYS_ABI_VERSION; }
+
+int32_t phys_create(const phys_config* cfg, phys_world** out) {
+    if (!cfg || !out) return fail(PHYS_ERR_INVALID_ARG, "null argument");
+    if (cfg->abi_version != PHYS_ABI_VERSION) return fail(PHYS_ERR_INVALID_ARG, "phys_config.abi_version mismatch");
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+        return fail(PHYS_ERR_NO_DEVICE, "no HIP device visible: libphysics_hip has no CPU fallback");
+    if (cfg->device < 0 || cfg->device >= count) return fail(PHYS_ERR_NO_DEVICE, "device ordinal out of range");
+    hipDeviceProp_t prop;
+    PHYS_HIP_TRY(hipGetDeviceProperties(&prop, cfg->device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(PHYS_ERR_NO_DEVICE, "device is not gfx950 (MI355X); this library carries gfx950 code only");
+    PHYS_HIP_TRY(hipSetDevice(cfg->device));
+    phys_world* w = new phys_world();
+    w->cfg = *cfg;
+    w->device = cfg->device;
+    hipError_t e = hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete w; return fail(PHYS_ERR_HIP, "hipStreamCreate failed"); }
+    e = w->counters.resize(1);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&w->h_counters, sizeof(StepCounters), hipHostMallocDefault);
+    if (e == hipSuccess) e = hipMemsetAsync(w->counters.p, 0, sizeof(StepCounters), w->stream);
+    if (e != hipSuccess) { delete w; return fail(PHYS_ERR_HIP, "counter allocation failed"); }
+    std::memset(w->h_counters, 0, sizeof(StepCounters));
+    *out = w;
+    return PHYS_OK;
+}
+
+int32_t phys_destroy(phys_world* w) {
+    if (!w) return PHYS_OK;
+    (void)hipSetDevice(w->device);
+    if (w->stream) (void)hipStreamSynchronize(w->stream);
+    DevBuf<float>* fb[] = {&w->pos, &w->rot, &w->lin, &w->ang, &w->force, &w->torque, &w->mass, &w->inv_mass,
+                           &w->inv_inertia, &w->half_extent, &w->aabb, &w->cg_x, &w->cg_r, &w->cg_p, &w->cg_ap,
+                           &w->cg_rhs, &w->cg_c, &w->cg_scratch, &w->man_normal, &w->man_points, &w->row_normal,
+                           &w->row_data, &w->row_acc};
+    for (auto* b : fb) b->free();
+    DevBuf<uint32_t>* ub[] = {&w->shape, &w->global_id, &w->cg_status, &w->cell_xyz, &w->bucket_of, &w->bucket_count,
+                              &w->bucket_start, &w->bucket_cursor, &w->sorted_ids, &w->scan_block_sums, &w->pairs,
+                              &w->man_a, &w->man_b, &w->man_count, &w->man_color, &w->row_a, &w->row_b, &w->row_count,
+                              &w->row_src, &w->cross_pairs};
+    for (auto* b : ub) b->free();
+    w->pair_keys.free(); w->man_prio.free(); w->body_top.free(); w->body_used.free();
+    w->d_constraints.free(); w->counters.free();
+    if (w->h_counters) (void)hipHostFree(w->h_counters);
+    if (w->stream) (void)hipStreamDestroy(w->stream);
+    delete w;
+    return PHYS_OK;
+}
+
+int32_t phys_set_bodies(phys_world* w, uint64_t n, const float* pos, const float* rot, const float* lin,
+                        const float* ang, const float* mass, const float* inertia, const uint32_t* shape_type,
+                        const float* half_extent) {
+    ENTER(w);
+    if (n && !pos) return fail(PHYS_ERR_INVALID_ARG, "pos is required");
+    if (n >= 0x7FFFFFFFull) return fail(PHYS_ERR_INVALID_ARG, "too many bodies (u32 indices)");
+    PHYS_HIP_TRY(hipStreamSynchronize(w->stream));
+    PHYS_HIP_TRY(w->pos.resize(3 * n)); PHYS_HIP_TRY(w->rot.resize(4 * n)); PHYS_HIP_TRY(w->lin.resize(3 * n));
+    PHYS_HIP_TRY(w->ang.resize(3 * n)); PHYS_HIP_TRY(w->force.resize(3 * n)); PHYS_HIP_TRY(w->torque.resize(3 * n));
+    PHYS_HIP_TRY(w->mass.resize(n)); PHYS_HIP_TRY(w->inv_mass.resize(n)); PHYS_HIP_TRY(w->inv_inertia.resize(9 * n));
+    PHYS_HIP_TRY(w->half_extent.resize(3 * n)); PHYS_HIP_TRY(w->aabb.resize(6 * n)); PHYS_HIP_TRY(w->shape.resize(n));
+    PHYS_HIP_TRY(w->global_id.resize(n));
+    w->n = n;
+    w->forces_dirty = false;
+    w->have_lambda = false;  // previous_solution: None
+    w->aabbs_valid = false;
+    if (n == 0) return PHYS_OK;
+
+    // host staging with RigidBody::new defaults (rigid_body.rs:64-76)
+    std::vector<float> h_rot(4 * n), h_mass(n), h_invm(n), h_inv(9 * n), h_zero3(3 * n, 0.0f), h_he(3 * n, 0.0f);
+    std::vector<uint32_t> h_shape(n, PHYS_SHAPE_NONE), h_gid(n);
+    w->singular_inertia = false;
+    w->all_diag_inertia = true;
+    for (uint64_t i = 0; i < n; ++i) {
+        if (rot) std::memcpy(&h_rot[4 * i], rot + 4 * i, 16);
+        else { h_rot[4 * i] = 0.0f; h_rot[4 * i + 1] = 0.0f; h_rot[4 * i + 2] = 0.0f; h_rot[4 * i + 3] = 1.0f; }
+        h_mass[i] = mass ? mass[i] : 1.0f;
+        h_invm[i] = 1.0f / h_mass[i];  // constraints.rs:75
+        m33 I, inv;
+        for (int k = 0; k < 9; ++k) I.m[k] = inertia ? inertia[9 * i + k] : ((k % 4 == 0) ? 1.0f : 0.0f);
+        // The reference inverts the (constant, world-frame) tensor every step (rigid_body.rs:31, quirk Q5);
+        // inverting once gives the same bits.
+        if (!m33_try_inverse(&I, &inv)) {
+            w->singular_inertia = true;
+            for (int k = 0; k < 9; ++k) inv.m[k] = 0.0f;
+        }
+        for (int k = 0; k < 9; ++k) {
+            h_inv[9 * i + k] = inv.m[k];
+            if (k % 4 != 0 && inv.m[k] != 0.0f) w->all_diag_inertia = false;
+        }
+        if (shape_type) h_shape[i] = shape_type[i];
+        if (half_extent) std::memcpy(&h_he[3 * i], half_extent + 3 * i, 12);
+        h_gid[i] = (uint32_t)i;
+    }
+    hipStream_t s = w->stream;
+    PHYS_HIP_TRY(hipMemcpyAsync(w->pos.p, pos, 12 * n, hipMemcpyHostToDevice, s));
+    PHYS_HIP_TRY(hipMemcpyAsync(w->rot.p, h_rot.data(), 16 * n, hipMemcpyHostToDevice, s));
+    PHYS_HIP_TRY(hipMemcpyAsync(w->lin.p, lin ? lin : h_zero3.data(), 12 * n, hipMemcpyHostToDevice, s));
+    PHYS_HIP_TRY(hipMemcpyAsync(w->ang.p, ang ? ang : h_zero3.data(), 12 * n, hipMemcpyHostToDevice, s));
+    PHYS_HIP_TRY(hipMemsetAsync(w->force.p, 0, 12 * n, s));
+    PHYS_HIP_TRY(hipMemsetAsync(w->torque.p, 0, 12 * n, s));
+    PHYS_HIP_TRY(hipMemcpyAsync(w->mass.p, h_mass.data(), 4 * n, hipMemcpyHostToDevice, s));
+    PHYS_HIP_TRY(hipMemcpyAsync(w->inv_mass.p, h_invm.data(), 4 * n, hipMemcpyHostToDevice, s));
+    PHYS_HIP_TRY(hipMemcpyAsync(w->inv_inertia.p, h_inv.data(), 36 * n, hipMemcpyHostToDevice, s));
+    PHYS_HIP_TRY(hipMemcpyAsync(w->half_extent.p, h_he.data(), 12 * n, hipMemcpyHostToDevice, s));
+    PHYS_HIP_TRY(hipMemcpyAsync(w->shape.p, h_shape.data(), 4 * n, hipMemcpyHostToDevice, s));
+    PHYS_HIP_TRY(hipMemcpyAsync(w->global_id.p, h_gid.data(), 4 * n, hipMemcpyHostToDevice, s));
+    PHYS_HIP_TRY(hipStreamSynchronize(s));  // staging vectors die here
+    if (w->cfg.flags & PHYS_FLAG_COLLISIONS) {
+        const int32_t rc = collision_alloc(w);
+        if (rc != PHYS_OK) return rc;
+    }
+    return PHYS_OK;
+}
+
+static int32_t add_constraint(phys_world* w, uint32_t kind, uint64_t body, const float t[3]) {
+    ENTER(w);
+    if (!t) return fail(PHYS_ERR_INVALID_ARG, "null target");
+    if (body >= w->n) return fail(PHYS_ERR_OUT_OF_RANGE, "body index out of range");
+    Constraint c;
+    c.kind = kind; c.body = (uint32_t)body;
+    c.target[0] = t[0]; c.target[1] = t[1]; c.target[2] = t[2];
+    w->constraints.push_back(c);
+    w->constraints_dirty = true;
+    return PHYS_OK;
+}
+int32_t phys_add_constraint_fix_point(phys_world* w, uint64_t body, const float target[3]) {
+    return add_constraint(w, 0u, body, target);
+}
+int32_t phys_add_constraint_fix_orientation(phys_world* w, uint64_t body, const float target_rpy[3]) {
+    return add_constraint(w, 1u, body, target_rpy);
+}
+int32_t phys_clear_constraints(phys_world* w) {
+    ENTER(w);
+    w->constraints.clear();
+    w->constraints_dirty = true;
+    w->have_lambda = false;
+    return PHYS_OK;
+}
+
+static int32_t apply_force(phys_world* w, uint64_t body, int mode, const float f[3], const float arg[3]) {
+    ENTER(w);
+    if (!f || (mode != 0 && !arg)) return fail(PHYS_ERR_INVALID_ARG, "null argument");
+    if (body >= w->n) return fail(PHYS_ERR_OUT_OF_RANGE, "body index out of range");
+    launch_apply_force_one(w, (uint32_t)body, mode, f, arg);
+    PHYS_HIP_TRY(hipGetLastError());
+    return PHYS_OK;
+}
+int32_t phys_apply_force_centre_of_gravity(phys_world* w, uint64_t body, const float force[3]) {
+    return apply_force(w, body, 0, force, nullptr);
+}
+int32_t phys_apply_force_at_position(phys_world* w, uint64_t body, const float force[3], const float point[3]) {
+    return apply_force(w, body, 1, force, point);
+}
+int32_t phys_apply_force_at_offset(phys_world* w, uint64_t body, const float force[3], const float offset[3]) {
+    return apply_force(w, body, 2, force, offset);
+}
+
+int32_t phys_apply_gravity(phys_world* w) {
+    ENTER(w);
+    launch_apply_gravity(w);
+    PHYS_HIP_TRY(hipGetLastError());
+    return PHYS_OK;
+}
+
+int32_t phys_step(phys_world* w, uint64_t dt_nanos) {
+    ENTER(w);
+    if (w->singular_inertia) return fail(PHYS_ERR_SINGULAR_INERTIA, "singular inertia tensor (reference: unwrap panic, rigid_body.rs:31)");
+    launch_step_full(w, duration_as_secs_f32(dt_nanos), /*gravity=*/false);
+    PHYS_HIP_TRY(hipGetLastError());
+    return PHYS_OK;
+}
+
+// one PhysicsState::update (physics.rs:41-55), enqueued without synchronising
+static int32_t enqueue_update(phys_world* w, float dt) {
+    const bool collisions = (w->cfg.flags & PHYS_FLAG_COLLISIONS) != 0;
+    const bool have_constraints = !w->constraints.empty();
+    bool gravity_pending = true;
+    if (have_constraints) {
+        // the constraint right-hand side reads Q = force/torque accumulators including gravity
+        // (constraints.rs:92-104), so gravity is materialised first, then lambda, then the scatter
+        launch_apply_gravity(w);
+        gravity_pending = false;
+        const int32_t rc = constraints_alloc(w);
+        if (rc != PHYS_OK) return rc;
+        launch_constraint_phase(w);
+    }
+    if (!collisions) {
+        launch_step_full(w, dt, gravity_pending);
+    } else {
+        PHYS_HIP_TRY(hipMemsetAsync(w->counters.p, 0, sizeof(StepCounters), w->stream));
+        launch_step_velocity_aabb(w, dt, gravity_pending);
+        launch_broadphase(w);
+        if (!(w->cfg.flags & PHYS_FLAG_BROADPHASE_ONLY)) {
+            launch_narrowphase(w);
+            launch_coloring(w);
+            launch_solver(w, dt);
+        }
+        launch_step_position(w, dt);
+    }
+    PHYS_HIP_TRY(hipGetLastError());
+    w->steps++;
+    return PHYS_OK;
+}
+
+int32_t phys_update_n(phys_world* w, uint64_t dt_nanos, uint32_t n) {
+    ENTER(w);
+    if (w->n == 0) return fail(PHYS_ERR_NO_BODIES, "update with no bodies (reference: index panic, physics.rs:48)");
+    if (w->singular_inertia) return fail(PHYS_ERR_SINGULAR_INERTIA, "singular inertia tensor (reference: unwrap panic, rigid_body.rs:31)");
+    const float dt = duration_as_secs_f32(dt_nanos);
+    for (uint32_t k = 0; k < n; ++k) {
+        const int32_t rc = enqueue_update(w, dt);
+        if (rc != PHYS_OK) return rc;
+    }
+    return PHYS_OK;
+}
+
+int32_t phys_update(phys_world* w, uint64_t dt_nanos) { return phys_update_n(w, dt_nanos, 1); }
+
+static int32_t fetch_counters(phys_world* w) {
+    PHYS_HIP_TRY(hipMemcpyAsync(w->h_counters, w->counters.p, sizeof(StepCounters), hipMemcpyDeviceToHost, w->stream));
+    PHYS_HIP_TRY(hipStreamSynchronize(w->stream));
+    return PHYS_OK;
+}
+
+int32_t phys_sync(phys_world* w) {
+    ENTER(w);
+    const int32_t rc = fetch_counters(w);
+    if (rc != PHYS_OK) return rc;
+    if (w->h_counters->overflow)
+        return fail(PHYS_ERR_CAPACITY, "pair/manifold/colour capacity exceeded: raise phys_config.max_pairs / max_manifolds");
+    return PHYS_OK;
+}
+
+static int32_t d2h(phys_world* w, void* dst, const void* src, size_t bytes) {
+    if (!dst || bytes == 0) return PHYS_OK;
+    PHYS_HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, w->stream));
+    return PHYS_OK;
+}
+
+int32_t phys_get_transforms(phys_world* w, float* pos_out, float* rot_out) {
+    ENTER(w);
+    int32_t rc = d2h(w, pos_out, w->pos.p, 12 * w->n); if (rc) return rc;
+    rc = d2h(w, rot_out, w->rot.p, 16 * w->n); if (rc) return rc;
+    PHYS_HIP_TRY(hipStreamSynchronize(w->stream));
+    return PHYS_OK;
+}
+int32_t phys_get_velocities(phys_world* w, float* lin_out, float* ang_out) {
+    ENTER(w);
+    int32_t rc = d2h(w, lin_out, w->lin.p, 12 * w->n); if (rc) return rc;
+    rc = d2h(w, ang_out, w->ang.p, 12 * w->n); if (rc) return rc;
+    PHYS_HIP_TRY(hipStreamSynchronize(w->stream));
+    return PHYS_OK;
+}
+int32_t phys_get_forces(phys_world* w, float* force_out, float* torque_out) {
+    ENTER(w);
+    int32_t rc = d2h(w, force_out, w->force.p, 12 * w->n); if (rc) return rc;
+    rc = d2h(w, torque_out, w->torque.p, 12 * w->n); if (rc) return rc;
+    PHYS_HIP_TRY(hipStreamSynchronize(w->stream));
+    return PHYS_OK;
+}
+
+int32_t phys_get_instance_matrices(phys_world* w, float* out) {
+    ENTER(w);
+    if (!out) return fail(PHYS_ERR_INVALID_ARG, "null output");
+    if (w->n == 0) return PHYS_OK;
+    float* d = nullptr;
+    PHYS_HIP_TRY(hipMalloc((void**)&d, 64 * w->n));
+    launch_instance_matrices(w, d);
+    hipError_t e = hipMemcpyAsync(out, d, 64 * w->n, hipMemcpyDeviceToHost, w->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(w->stream);
+    (void)hipFree(d);
+    PHYS_HIP_TRY(e);
+    return PHYS_OK;
+}
+
+int32_t phys_get_lambda(phys_world* w, float* lambda_out, uint64_t cap, uint64_t* n_rows) {
+    ENTER(w);
+    if (!n_rows) return fail(PHYS_ERR_INVALID_ARG, "null n_rows");
+    PHYS_HIP_TRY(hipStreamSynchronize(w->stream));
+    const uint64_t rows = w->have_lambda ? 3 * (uint64_t)w->constraints.size() : 0;
+    *n_rows = rows;
+    if (lambda_out && rows) {
+        const uint64_t m = rows < cap ? rows : cap;
+        PHYS_HIP_TRY(hipMemcpy(lambda_out, w->cg_x.p, 4 * m, hipMemcpyDeviceToHost));
+    }
+    return PHYS_OK;
+}
+
+int32_t phys_get_aabbs(phys_world* w, float* out) {
+    ENTER(w);
+    if (!out) return fail(PHYS_ERR_INVALID_ARG, "null output");
+    launch_aabb_only(w);
+    int32_t rc = d2h(w, out, w->aabb.p, 24 * w->n); if (rc) return rc;
+    PHYS_HIP_TRY(hipStreamSynchronize(w->stream));
+    return PHYS_OK;
+}
+
+int32_t phys_broadphase(phys_world* w, uint32_t* pairs_out, uint64_t cap, uint64_t* n_pairs) {
+    ENTER(w);
+    if (!n_pairs) return fail(PHYS_ERR_INVALID_ARG, "null n_pairs");
+    if (!(w->cfg.flags & PHYS_FLAG_COLLISIONS)) return fail(PHYS_ERR_UNSUPPORTED, "world created without PHYS_FLAG_COLLISIONS");
+    if (w->n == 0) { *n_pairs = 0; return PHYS_OK; }
+    PHYS_HIP_TRY(hipMemsetAsync(w->counters.p, 0, sizeof(StepCounters), w->stream));
+    launch_aabb_only(w);
+    launch_broadphase(w);
+    PHYS_HIP_TRY(hipGetLastError());
+    return sorted_pairs_to_host(w, pairs_out, cap, n_pairs);
+}
+
+int32_t phys_get_manifolds(phys_world* w, uint32_t* ids_out, uint32_t* counts_out, float* normals_out,
+                           float* points_out, uint64_t cap, uint64_t* n_manifolds) {
+    ENTER(w);
+    if (!n_manifolds) return fail(PHYS_ERR_INVALID_ARG, "null n_manifolds");
+    int32_t rc = fetch_counters(w); if (rc) return rc;
+    const uint64_t m = w->h_counters->n_manifolds < w->max_manifolds ? w->h_counters->n_manifolds : w->max_manifolds;
+    *n_manifolds = m;
+    if (m == 0 || (!ids_out && !counts_out && !normals_out && !points_out)) return PHYS_OK;
+    // read back in storage order, sort by (a, b) on the host (a read-out convenience, not the hot path)
+    std::vector<uint32_t> a(m), b(m), c(m);
+    std::vector<float> nrm(3 * m), pts(16 * m);
+    PHYS_HIP_TRY(hipMemcpy(a.data(), w->man_a.p, 4 * m, hipMemcpyDeviceToHost));
+    PHYS_HIP_TRY(hipMemcpy(b.data(), w->man_b.p, 4 * m, hipMemcpyDeviceToHost));
+    PHYS_HIP_TRY(hipMemcpy(c.data(), w->man_count.p, 4 * m, hipMemcpyDeviceToHost));
+    PHYS_HIP_TRY(hipMemcpy(nrm.data(), w->man_normal.p, 12 * m, hipMemcpyDeviceToHost));
+    PHYS_HIP_TRY(hipMemcpy(pts.data(), w->man_points.p, 64 * m, hipMemcpyDeviceToHost));
+    std::vector<uint64_t> order(m);
+    for (uint64_t k = 0; k < m; ++k) order[k] = k;
+    std::sort(order.begin(), order.end(), [&](uint64_t x, uint64_t y) { return a[x] < a[y] || (a[x] == a[y] && b[x] < b[y]); });
+    for (uint64_t k = 0; k < m && k < cap; ++k) {
+        const uint64_t s = order[k];
+        if (ids_out) { ids_out[2 * k] = a[s]; ids_out[2 * k + 1] = b[s]; }
+        if (counts_out) counts_out[k] = c[s];
+        if (normals_out) std::memcpy(normals_out + 3 * k, &nrm[3 * s], 12);
+        if (points_out) std::memcpy(points_out + 16 * k, &pts[16 * s], 64);
+    }
+    return PHYS_OK;
+}
+
+int32_t phys_get_stats(phys_world* w, phys_stats* out) {
+    ENTER(w);
+    if (!out) return fail(PHYS_ERR_INVALID_ARG, "null output");
+    int32_t rc = fetch_counters(w); if (rc) return rc;
+    std::memset(out, 0, sizeof(*out));
+    const StepCounters& c = *w->h_counters;
+    out->n_bodies = w->n;
+    out->n_pairs = c.n_pairs;
+    out->n_manifolds = c.n_manifolds;
+    out->n_contacts = c.n_contacts;
+    out->n_colors = c.n_colors;
+    out->color_rounds = c.color_rounds;
+    if (w->cg_status.p) {
+        uint32_t st[2] = {1, 0};
+        PHYS_HIP_TRY(hipMemcpy(st, w->cg_status.p, 8, hipMemcpyDeviceToHost));
+        out->cg_converged = (int32_t)st[0];
+        out->cg_iterations = st[1];
+    } else {
+        out->cg_converged = 1;
+    }
+    out->steps = w->steps;
+    out->overflow = c.overflow;
+    return PHYS_OK;
+}
+
+int32_t phys_get_device_view(phys_world* w, phys_device_view* out) {
+    ENTER(w);
+    if (!out) return fail(PHYS_ERR_INVALID_ARG, "null output");
+    out->n = w->n;
+    out->pos = w->pos.p; out->rot = w->rot.p; out->lin_vel = w->lin.p; out->ang_vel = w->ang.p;
+    out->aabb = w->aabb.p;
+    out->stream = (void*)w->stream;
+    return PHYS_OK;
+}
+
+int32_t phys_set_global_ids(phys_world* w, const uint32_t* global_ids) {
+    ENTER(w);
+    if (!global_ids) return fail(PHYS_ERR_INVALID_ARG, "null ids");
+    PHYS_HIP_TRY(hipMemcpyAsync(w->global_id.p, global_ids, 4 * w->n, hipMemcpyHostToDevice, w->stream));
+    PHYS_HIP_TRY(hipStreamSynchronize(w->stream));
+    return PHYS_OK;
+}
+
+int32_t phys_halo_pack(phys_world* w, float x_lo, float x_hi, void* dev_records_out, uint64_t cap, uint64_t* n_records) {
+    ENTER(w);
+    return halo_pack(w, x_lo, x_hi, dev_records_out, cap, n_records);
+}
+int32_t phys_halo_pairs(phys_world* w, const void* dev_remote_records, uint64_t n_remote, uint64_t* n_cross_pairs) {
+    ENTER(w);
+    return halo_pairs(w, dev_remote_records, n_remote, n_cross_pairs);
+}
+int32_t phys_get_cross_pairs(phys_world* w, uint32_t* pairs_out, uint64_t cap, uint64_t* n_pairs) {
+    ENTER(w);
+    if (!n_pairs) return fail(PHYS_ERR_INVALID_ARG, "null n_pairs");
+    int32_t rc = fetch_counters(w); if (rc) return rc;
+    const uint64_t m = w->h_counters->n_cross_pairs < w->max_cross_pairs ? w->h_counters->n_cross_pairs : w->max_cross_pairs;
+    *n_pairs = m;
+    if (pairs_out && m) {
+        std::vector<uint64_t> keys(m);
+        std::vector<uint32_t> raw(2 * m);
+        PHYS_HIP_TRY(hipMemcpy(raw.data(), w->cross_pairs.p, 8 * m, hipMemcpyDeviceToHost));
+        for (uint64_t k = 0; k < m; ++k) keys[k] = ((uint64_t)raw[2 * k] << 32) | raw[2 * k + 1];
+        std::sort(keys.begin(), keys.end());
+        for (uint64_t k = 0; k < m && k < cap; ++k) { pairs_out[2 * k] = (uint32_t)(keys[k] >> 32); pairs_out[2 * k + 1] = (uint32_t)keys[k]; }
+    }
+    return PHYS_OK;
+}
+
+}  // extern "C"

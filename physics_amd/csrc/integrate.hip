@@ -1,0 +1,330 @@
+// integrate.hip — gravity + semi-implicit Euler kernels for gfx950.
+//
+// Replaces PhysicsState::apply_gravity (reference src/physics.rs:87-94) and RigidBody::step
+// (src/physics/rigid_body.rs:24-40), operation for operation (quirks Q1, Q2, Q5, Q6, Q9), on SoA
+// arrays. Purely HBM-bound: one lane per body, every attribute read once and written once.
+// Algorithmic bytes per body: fused gravity+step 120 B (R 68: pos 12, rot 16, v 12,
+// w 12, mass 4, inv-inertia diag 12; W 52); +36 B when the full 3x3 inverse inertia is needed; +48 B
+// when the force/torque accumulators are live (R 24 + W 24 zeroing).
+#include "kernels.hpp"
+
+namespace phys {
+
+struct StepParams {
+    uint32_t n;
+    float dt;
+    float g_force[3];   // gravity force (physics.rs:90)
+    float g_torque[3];  // offset x force (rigid_body.rs:60), same for every body
+};
+
+__device__ __forceinline__ v3 ld3(const float* __restrict__ p, uint32_t i) {
+    return v3_make(p[3 * i], p[3 * i + 1], p[3 * i + 2]);
+}
+__device__ __forceinline__ void st3(float* __restrict__ p, uint32_t i, v3 v) {
+    p[3 * i] = v.x; p[3 * i + 1] = v.y; p[3 * i + 2] = v.z;
+}
+
+// velocity half of RigidBody::step: rigid_body.rs:27, 30-31
+template <bool DIAG>
+__device__ __forceinline__ void integrate_velocity(v3 F, v3 T, float mass, const float* __restrict__ inv_inertia,
+                                                   uint32_t i, float dt, v3& v, v3& w) {
+    v.x = v.x + F.x / mass * dt;
+    v.y = v.y + F.y / mass * dt;
+    v.z = v.z + F.z / mass * dt;
+    const v3 L = v3_make(T.x * dt, T.y * dt, T.z * dt);
+    v3 dw;
+    if (DIAG) {
+        // off-diagonals are exactly zero: the gemv row sum reduces to the diagonal product
+        dw = v3_make(inv_inertia[9 * i + 0] * L.x, inv_inertia[9 * i + 4] * L.y, inv_inertia[9 * i + 8] * L.z);
+    } else {
+        m33 I;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) I.m[k] = inv_inertia[9 * i + k];
+        dw = m33_mul_v3(&I, L);
+    }
+    w = v3_add(w, dw);
+}
+
+// position half of RigidBody::step: rigid_body.rs:28, 32-37
+template <bool EXACT_ROT>
+__device__ __forceinline__ void integrate_position(float dt, v3 v, v3 w, v3& x, quat& q) {
+    x.x = x.x + v.x * dt;
+    x.y = x.y + v.y * dt;
+    x.z = x.z + v.z * dt;
+    if (w.x != 0.0f || w.y != 0.0f || w.z != 0.0f) {
+        const float nrm = v3_norm(w);
+        const v3 a = v3_div(w, nrm);
+        const float theta = nrm * dt;
+        const float scale = EXACT_ROT ? theta : det_sinf(theta * 0.5f);  // quirk Q1
+        const v3 u = v3_make((a.x * scale) / 2.0f, (a.y * scale) / 2.0f, (a.z * scale) / 2.0f);
+        const float nn = v3_dot(u, u);
+        const float eps = 1.1920929e-7f;  // f32::EPSILON
+        quat dq;
+        if (nn <= eps * eps) {
+            dq.i = 0.0f; dq.j = 0.0f; dq.k = 0.0f; dq.w = 1.0f;
+        } else {
+            const float n = det_sqrtf(nn);
+            const float f = 1.0f * det_sinf(n) / n;
+            dq.i = u.x * f; dq.j = u.y * f; dq.k = u.z * f;
+            dq.w = 1.0f * det_cosf(n);
+        }
+        q = quat_mul(dq, q);  // quirk Q6: never renormalised
+    }
+}
+
+// One kernel = [apply_gravity] + RigidBody::step for every body.
+// FORCES: read + zero the force/torque accumulators; otherwise they are known to be zero.
+// GRAVITY: fold apply_gravity in (update path); off for a bare phys_step.
+template <bool FORCES, bool GRAVITY, bool DIAG, bool EXACT_ROT>
+__global__ __launch_bounds__(256) void k_step_full(StepParams sp, float* __restrict__ pos, float* __restrict__ rot,
+                                                   float* __restrict__ lin, float* __restrict__ ang,
+                                                   float* __restrict__ force, float* __restrict__ torque,
+                                                   const float* __restrict__ mass,
+                                                   const float* __restrict__ inv_inertia) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= sp.n) return;
+    v3 F = v3_make(0.0f, 0.0f, 0.0f), T = v3_make(0.0f, 0.0f, 0.0f);
+    if (FORCES) { F = ld3(force, i); T = ld3(torque, i); }
+    if (GRAVITY) {
+        // apply_force_at_offset: torque += offset x F; force += F
+        T = v3_add(T, v3_make(sp.g_torque[0], sp.g_torque[1], sp.g_torque[2]));
+        F = v3_add(F, v3_make(sp.g_force[0], sp.g_force[1], sp.g_force[2]));
+    }
+    v3 v = ld3(lin, i), w = ld3(ang, i), x = ld3(pos, i);
+    float4 qq = reinterpret_cast<float4*>(rot)[i];
+    quat q; q.i = qq.x; q.j = qq.y; q.k = qq.z; q.w = qq.w;
+    integrate_velocity<DIAG>(F, T, mass[i], inv_inertia, i, sp.dt, v, w);
+    integrate_position<EXACT_ROT>(sp.dt, v, w, x, q);
+    st3(lin, i, v); st3(ang, i, w); st3(pos, i, x);
+    reinterpret_cast<float4*>(rot)[i] = make_float4(q.i, q.j, q.k, q.w);
+    if (FORCES) { st3(force, i, v3_make(0.0f, 0.0f, 0.0f)); st3(torque, i, v3_make(0.0f, 0.0f, 0.0f)); }
+}
+
+// collision mode, first half: [gravity] + velocity update + fattened AABB + largest-extent reduction
+template <bool FORCES, bool GRAVITY, bool DIAG>
+__global__ __launch_bounds__(256) void k_step_velocity_aabb(StepParams sp, const float* __restrict__ pos,
+                                                            const float* __restrict__ rot, float* __restrict__ lin,
+                                                            float* __restrict__ ang, float* __restrict__ force,
+                                                            float* __restrict__ torque, const float* __restrict__ mass,
+                                                            const float* __restrict__ inv_inertia,
+                                                            const uint32_t* __restrict__ shape,
+                                                            const float* __restrict__ half_extent, float margin,
+                                                            float* __restrict__ aabb, StepCounters* __restrict__ ctr) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    float ext = 0.0f;
+    if (i < sp.n) {
+        v3 F = v3_make(0.0f, 0.0f, 0.0f), T = v3_make(0.0f, 0.0f, 0.0f);
+        if (FORCES) { F = ld3(force, i); T = ld3(torque, i); }
+        if (GRAVITY) {
+            T = v3_add(T, v3_make(sp.g_torque[0], sp.g_torque[1], sp.g_torque[2]));
+            F = v3_add(F, v3_make(sp.g_force[0], sp.g_force[1], sp.g_force[2]));
+        }
+        v3 v = ld3(lin, i), w = ld3(ang, i);
+        integrate_velocity<DIAG>(F, T, mass[i], inv_inertia, i, sp.dt, v, w);
+        st3(lin, i, v); st3(ang, i, w);
+        if (FORCES) { st3(force, i, v3_make(0.0f, 0.0f, 0.0f)); st3(torque, i, v3_make(0.0f, 0.0f, 0.0f)); }
+        const v3 x = ld3(pos, i);
+        const float4 qq = reinterpret_cast<const float4*>(rot)[i];
+        quat q; q.i = qq.x; q.j = qq.y; q.k = qq.z; q.w = qq.w;
+        const uint32_t type = shape[i];
+        const aabb_t b = body_aabb(x, q, ld3(half_extent, i), type, margin);
+        aabb[6 * i + 0] = b.lo.x; aabb[6 * i + 1] = b.lo.y; aabb[6 * i + 2] = b.lo.z;
+        aabb[6 * i + 3] = b.hi.x; aabb[6 * i + 4] = b.hi.y; aabb[6 * i + 5] = b.hi.z;
+        if (type != PHYS_SPEC_SHAPE_NONE)
+            ext = det_maxf(b.hi.x - b.lo.x, det_maxf(b.hi.y - b.lo.y, b.hi.z - b.lo.z));
+    }
+    // largest extent: wave max by shuffles, one atomic per wave (max is order-independent => deterministic)
+    uint32_t bits = __float_as_uint(ext > 0.0f ? ext : 0.0f);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const uint32_t o = (uint32_t)__shfl_xor((int)bits, off, 64);
+        bits = o > bits ? o : bits;
+    }
+    if ((threadIdx.x & 63) == 0 && bits != 0) atomicMax(&ctr->max_extent_bits, bits);
+}
+
+// AABBs only (phys_broadphase / phys_get_aabbs on the current poses)
+__global__ __launch_bounds__(256) void k_aabb_only(uint32_t n, const float* __restrict__ pos,
+                                                   const float* __restrict__ rot, const uint32_t* __restrict__ shape,
+                                                   const float* __restrict__ half_extent, float margin,
+                                                   float* __restrict__ aabb, StepCounters* __restrict__ ctr) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    float ext = 0.0f;
+    if (i < n) {
+        const v3 x = ld3(pos, i);
+        const float4 qq = reinterpret_cast<const float4*>(rot)[i];
+        quat q; q.i = qq.x; q.j = qq.y; q.k = qq.z; q.w = qq.w;
+        const uint32_t type = shape[i];
+        const aabb_t b = body_aabb(x, q, ld3(half_extent, i), type, margin);
+        aabb[6 * i + 0] = b.lo.x; aabb[6 * i + 1] = b.lo.y; aabb[6 * i + 2] = b.lo.z;
+        aabb[6 * i + 3] = b.hi.x; aabb[6 * i + 4] = b.hi.y; aabb[6 * i + 5] = b.hi.z;
+        if (type != PHYS_SPEC_SHAPE_NONE)
+            ext = det_maxf(b.hi.x - b.lo.x, det_maxf(b.hi.y - b.lo.y, b.hi.z - b.lo.z));
+    }
+    uint32_t bits = __float_as_uint(ext > 0.0f ? ext : 0.0f);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const uint32_t o = (uint32_t)__shfl_xor((int)bits, off, 64);
+        bits = o > bits ? o : bits;
+    }
+    if ((threadIdx.x & 63) == 0 && bits != 0) atomicMax(&ctr->max_extent_bits, bits);
+}
+
+// collision mode, second half: position + rotation update
+template <bool EXACT_ROT>
+__global__ __launch_bounds__(256) void k_step_position(uint32_t n, float dt, float* __restrict__ pos,
+                                                       float* __restrict__ rot, const float* __restrict__ lin,
+                                                       const float* __restrict__ ang) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    v3 x = ld3(pos, i);
+    const v3 v = ld3(lin, i), w = ld3(ang, i);
+    float4 qq = reinterpret_cast<float4*>(rot)[i];
+    quat q; q.i = qq.x; q.j = qq.y; q.k = qq.z; q.w = qq.w;
+    integrate_position<EXACT_ROT>(dt, v, w, x, q);
+    st3(pos, i, x);
+    reinterpret_cast<float4*>(rot)[i] = make_float4(q.i, q.j, q.k, q.w);
+}
+
+// PhysicsState::apply_gravity as a stand-alone call (physics.rs:87-94): accumulators += gravity
+__global__ __launch_bounds__(256) void k_apply_gravity(StepParams sp, float* __restrict__ force,
+                                                       float* __restrict__ torque) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= sp.n) return;
+    v3 F = ld3(force, i), T = ld3(torque, i);
+    T = v3_add(T, v3_make(sp.g_torque[0], sp.g_torque[1], sp.g_torque[2]));
+    F = v3_add(F, v3_make(sp.g_force[0], sp.g_force[1], sp.g_force[2]));
+    st3(force, i, F); st3(torque, i, T);
+}
+
+// RigidBody::apply_force_* on one body (rigid_body.rs:43-62); mode 0 centre, 1 at position, 2 at offset
+__global__ void k_apply_force_one(uint32_t body, int mode, v3 f, v3 arg, const float* __restrict__ pos,
+                                  float* __restrict__ force, float* __restrict__ torque) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    v3 F = ld3(force, body), T = ld3(torque, body);
+    if (mode == 1) T = v3_add(T, v3_cross(v3_sub(arg, ld3(pos, body)), f));
+    if (mode == 2) T = v3_add(T, v3_cross(arg, f));
+    F = v3_add(F, f);
+    st3(force, body, F); st3(torque, body, T);
+}
+
+// Instance::to_raw (graphics.rs:13-21): column-major T(p) * R(q), 16 floats per body (row N1)
+__global__ __launch_bounds__(256) void k_instance_matrices(uint32_t n, const float* __restrict__ pos,
+                                                           const float* __restrict__ rot, float* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const v3 x = ld3(pos, i);
+    const float4 qq = reinterpret_cast<const float4*>(rot)[i];
+    quat q; q.i = qq.x; q.j = qq.y; q.k = qq.z; q.w = qq.w;
+    m33 R;
+    quat_to_m33(q, &R);
+    float4* o = reinterpret_cast<float4*>(out) + 4 * (size_t)i;
+    o[0] = make_float4(R.m[0], R.m[3], R.m[6], 0.0f);
+    o[1] = make_float4(R.m[1], R.m[4], R.m[7], 0.0f);
+    o[2] = make_float4(R.m[2], R.m[5], R.m[8], 0.0f);
+    o[3] = make_float4(x.x, x.y, x.z, 1.0f);
+}
+
+static inline StepParams make_params(const phys_world* w, float dt) {
+    StepParams sp;
+    sp.n = (uint32_t)w->n;
+    sp.dt = dt;
+    const float* F = w->cfg.gravity_force;
+    const float* o = w->cfg.gravity_offset;
+    for (int k = 0; k < 3; ++k) sp.g_force[k] = F[k];
+    // offset.cross(&force), rigid_body.rs:60
+    sp.g_torque[0] = o[1] * F[2] - o[2] * F[1];
+    sp.g_torque[1] = o[2] * F[0] - o[0] * F[2];
+    sp.g_torque[2] = o[0] * F[1] - o[1] * F[0];
+    return sp;
+}
+
+static inline dim3 grid_for(uint64_t n) { return dim3((unsigned)((n + 255) / 256)); }
+
+template <bool FORCES, bool GRAVITY>
+static void launch_full(phys_world* w, const StepParams& sp) {
+    const bool diag = w->all_diag_inertia;
+    const bool exact = (w->cfg.flags & PHYS_FLAG_EXACT_ROTATION) != 0;
+    const dim3 g = grid_for(w->n), b(256);
+#define LAUNCH(D, E)                                                                                              \
+    hipLaunchKernelGGL((k_step_full<FORCES, GRAVITY, D, E>), g, b, 0, w->stream, sp, w->pos.p, w->rot.p, w->lin.p, \
+                       w->ang.p, w->force.p, w->torque.p, w->mass.p, w->inv_inertia.p)
+    if (diag && exact) LAUNCH(true, true);
+    else if (diag) LAUNCH(true, false);
+    else if (exact) LAUNCH(false, true);
+    else LAUNCH(false, false);
+#undef LAUNCH
+}
+
+// gravity (optional) + RigidBody::step for every body, one launch
+void launch_step_full(phys_world* w, float dt, bool gravity) {
+    if (w->n == 0) return;
+    const StepParams sp = make_params(w, dt);
+    if (w->forces_dirty) { if (gravity) launch_full<true, true>(w, sp); else launch_full<true, false>(w, sp); }
+    else                 { if (gravity) launch_full<false, true>(w, sp); else launch_full<false, false>(w, sp); }
+    w->forces_dirty = false;
+}
+
+void launch_step_velocity_aabb(phys_world* w, float dt, bool gravity) {
+    if (w->n == 0) return;
+    const StepParams sp = make_params(w, dt);
+    const dim3 g = grid_for(w->n), b(256);
+    const bool diag = w->all_diag_inertia;
+    const float margin = w->cfg.contact_margin;
+#define LAUNCH(F, G, D)                                                                                            \
+    hipLaunchKernelGGL((k_step_velocity_aabb<F, G, D>), g, b, 0, w->stream, sp, w->pos.p, w->rot.p, w->lin.p,      \
+                       w->ang.p, w->force.p, w->torque.p, w->mass.p, w->inv_inertia.p, w->shape.p,                \
+                       w->half_extent.p, margin, w->aabb.p, w->counters.p)
+    const int sel = (w->forces_dirty ? 4 : 0) | (gravity ? 2 : 0) | (diag ? 1 : 0);
+    switch (sel) {
+        case 0: LAUNCH(false, false, false); break;
+        case 1: LAUNCH(false, false, true); break;
+        case 2: LAUNCH(false, true, false); break;
+        case 3: LAUNCH(false, true, true); break;
+        case 4: LAUNCH(true, false, false); break;
+        case 5: LAUNCH(true, false, true); break;
+        case 6: LAUNCH(true, true, false); break;
+        default: LAUNCH(true, true, true); break;
+    }
+#undef LAUNCH
+    w->forces_dirty = false;
+    w->aabbs_valid = true;
+}
+
+void launch_aabb_only(phys_world* w) {
+    if (w->n == 0) return;
+    hipLaunchKernelGGL(k_aabb_only, grid_for(w->n), dim3(256), 0, w->stream, (uint32_t)w->n, w->pos.p, w->rot.p,
+                       w->shape.p, w->half_extent.p, w->cfg.contact_margin, w->aabb.p, w->counters.p);
+    w->aabbs_valid = true;
+}
+
+void launch_step_position(phys_world* w, float dt) {
+    if (w->n == 0) return;
+    const dim3 g = grid_for(w->n), b(256);
+    if (w->cfg.flags & PHYS_FLAG_EXACT_ROTATION)
+        hipLaunchKernelGGL((k_step_position<true>), g, b, 0, w->stream, (uint32_t)w->n, dt, w->pos.p, w->rot.p, w->lin.p, w->ang.p);
+    else
+        hipLaunchKernelGGL((k_step_position<false>), g, b, 0, w->stream, (uint32_t)w->n, dt, w->pos.p, w->rot.p, w->lin.p, w->ang.p);
+    w->aabbs_valid = false;
+}
+
+void launch_apply_gravity(phys_world* w) {
+    if (w->n == 0) return;
+    const StepParams sp = make_params(w, 0.0f);
+    hipLaunchKernelGGL(k_apply_gravity, grid_for(w->n), dim3(256), 0, w->stream, sp, w->force.p, w->torque.p);
+    w->forces_dirty = true;
+}
+
+void launch_apply_force_one(phys_world* w, uint32_t body, int mode, const float f[3], const float arg[3]) {
+    const v3 fv = v3_make(f[0], f[1], f[2]);
+    const v3 av = arg ? v3_make(arg[0], arg[1], arg[2]) : v3_make(0.0f, 0.0f, 0.0f);
+    hipLaunchKernelGGL(k_apply_force_one, dim3(1), dim3(64), 0, w->stream, body, mode, fv, av, w->pos.p, w->force.p, w->torque.p);
+    w->forces_dirty = true;
+}
+
+void launch_instance_matrices(phys_world* w, float* d_out) {
+    if (w->n == 0) return;
+    hipLaunchKernelGGL(k_instance_matrices, grid_for(w->n), dim3(256), 0, w->stream, (uint32_t)w->n, w->pos.p, w->rot.p, d_out);
+}
+
+}  // namespace phys

@@ -1,0 +1,43 @@
+// kernels.hpp — shared includes and the host-side launch interface between the translation units
+// of libphysics_hip.so. Every launch_* enqueues on w->stream and returns without synchronising.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "../../include/spec/collide.h"
+#include "../../include/spec/contact_solve.h"
+#include "../../include/spec/det_math.h"
+#include "../../include/spec/vec.h"
+#include "world.hpp"
+
+static_assert(PHYS_MAX_COLORS == phys::kMaxColors, "colour limit mismatch");
+
+namespace phys {
+
+// integrate.hip
+void launch_step_full(phys_world* w, float dt, bool gravity);
+void launch_step_velocity_aabb(phys_world* w, float dt, bool gravity);
+void launch_aabb_only(phys_world* w);
+void launch_step_position(phys_world* w, float dt);
+void launch_apply_gravity(phys_world* w);
+void launch_apply_force_one(phys_world* w, uint32_t body, int mode, const float f[3], const float arg[3]);
+void launch_instance_matrices(phys_world* w, float* d_out);
+
+// broadphase.hip
+int32_t collision_alloc(phys_world* w);
+void launch_broadphase(phys_world* w);
+int32_t sorted_pairs_to_host(phys_world* w, uint32_t* pairs_out, uint64_t cap, uint64_t* n_pairs);
+
+// narrowphase.hip / solver.hip
+void launch_narrowphase(phys_world* w);
+void launch_coloring(phys_world* w);
+void launch_solver(phys_world* w, float dt);
+
+// constraints.hip
+int32_t constraints_alloc(phys_world* w);
+void launch_constraint_phase(phys_world* w);
+
+// halo.hip
+int32_t halo_pack(phys_world* w, float x_lo, float x_hi, void* dev_out, uint64_t cap, uint64_t* n_records);
+int32_t halo_pairs(phys_world* w, const void* dev_remote, uint64_t n_remote, uint64_t* n_cross);
+
+}  // namespace phys

@@ -1,0 +1,133 @@
+// world.hpp — device-resident state of one phys_world (MI355X / gfx950).
+//
+// Layout in HBM: structure-of-arrays, one array per body attribute, so a wave reading attribute k of
+// bodies [64w, 64w+64) touches one contiguous span (3-float attributes: 768 B per wave, quaternions:
+// 1 KiB as dwordx4). Everything stays resident across steps; the host only sees what it asks for.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/physics_hip.h"
+
+namespace phys {
+
+constexpr int kMaxColors = 64;  // == PHYS_MAX_COLORS of include/spec/contact_solve.h
+
+void set_error(const std::string& msg);
+const char* get_error();
+
+#define PHYS_HIP_TRY(expr)                                                                          \
+    do {                                                                                            \
+        hipError_t _e = (expr);                                                                     \
+        if (_e != hipSuccess) {                                                                     \
+            phys::set_error(std::string(#expr) + ": " + hipGetErrorString(_e));                     \
+            return PHYS_ERR_HIP;                                                                    \
+        }                                                                                           \
+    } while (0)
+
+template <typename T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    hipError_t resize(size_t count) {
+        if (count <= n && p) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+        if (count == 0) return hipSuccess;
+        hipError_t e = hipMalloc((void**)&p, count * sizeof(T));
+        if (e == hipSuccess) n = count;
+        return e;
+    }
+    void free() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+};
+
+// device-side counters of the collision pipeline (one 256-B block, zeroed per step by one memset)
+struct StepCounters {
+    uint32_t n_pairs;        // candidate pairs written
+    uint32_t n_manifolds;    // manifolds written (body-body + ground)
+    uint32_t n_contacts;     // contact points
+    uint32_t n_uncolored;    // manifolds still uncoloured (colouring loop)
+    uint32_t n_colors;       // colours in use
+    uint32_t color_rounds;
+    uint32_t overflow;       // bit 0 pairs, bit 1 manifolds, bit 2 colours, bit 3 cross pairs
+    uint32_t max_extent_bits;  // float bits of the largest AABB extent (positive floats order as uints)
+    uint32_t n_halo;         // halo records packed
+    uint32_t n_cross_pairs;
+    uint32_t color_count[kMaxColors];  // manifolds per colour
+    uint32_t color_start[kMaxColors + 1];
+    uint32_t color_cursor[kMaxColors];
+};
+
+struct Constraint {
+    uint32_t kind;  // 0 fix point, 1 fix orientation
+    uint32_t body;
+    float target[3];
+};
+
+}  // namespace phys
+
+struct phys_world {
+    phys_config cfg;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    uint64_t n = 0;
+    uint64_t steps = 0;
+    bool forces_dirty = false;      // force / torque arrays hold non-zero accumulators
+    bool singular_inertia = false;  // some body's inertia tensor has det == 0 (reference panics in step)
+    bool all_diag_inertia = true;
+    bool aabbs_valid = false;
+
+    // body SoA
+    phys::DevBuf<float> pos, rot, lin, ang, force, torque, mass, inv_mass, inv_inertia, half_extent, aabb;
+    phys::DevBuf<uint32_t> shape;
+    phys::DevBuf<uint32_t> global_id;
+
+    // constraints (A3-A7)
+    std::vector<phys::Constraint> constraints;
+    phys::DevBuf<phys::Constraint> d_constraints;
+    bool constraints_dirty = false;
+    bool have_lambda = false;  // previous_solution.is_some()
+    phys::DevBuf<float> cg_x, cg_r, cg_p, cg_ap, cg_rhs, cg_c, cg_scratch;
+    phys::DevBuf<uint32_t> cg_status;  // [0] converged flag, [1] iterations
+    uint32_t last_cg_iterations = 0;
+    int32_t last_cg_converged = 1;
+
+    // collision pipeline (A10-A12)
+    uint64_t max_pairs = 0, max_manifolds = 0;
+    uint32_t grid_table_size = 0;  // hashed-grid buckets (power of two)
+    phys::DevBuf<phys::StepCounters> counters;
+    phys::DevBuf<uint32_t> cell_xyz;     // 3n: integer cell coordinates of every body
+    phys::DevBuf<uint32_t> bucket_of;    // n
+    phys::DevBuf<uint32_t> bucket_count, bucket_start, bucket_cursor;  // table
+    phys::DevBuf<uint32_t> sorted_ids;   // n: body ids grouped by bucket
+    phys::DevBuf<uint32_t> scan_block_sums;
+    phys::DevBuf<uint32_t> pairs;        // 2 * max_pairs
+    phys::DevBuf<uint64_t> pair_keys;    // sort scratch for phys_broadphase
+    // manifolds, geometry stage (storage order = emission order, arbitrary)
+    phys::DevBuf<uint32_t> man_a, man_b, man_count, man_color;
+    phys::DevBuf<float> man_normal;      // 3 per manifold
+    phys::DevBuf<float> man_points;      // 16 per manifold: 4 x (xyz, depth)
+    phys::DevBuf<uint64_t> man_prio;
+    // colouring state
+    phys::DevBuf<unsigned long long> body_top, body_used;
+    // solver rows, colour-sorted SoA
+    phys::DevBuf<uint32_t> row_a, row_b, row_count, row_src;
+    phys::DevBuf<float> row_normal;  // 3 per manifold (SoA planes)
+    phys::DevBuf<float> row_data;    // per point-slot planes: rA(3) rB(3) nmass tmass0 tmass1 bias
+    phys::DevBuf<float> row_acc;     // per point-slot planes: pn pt0 pt1
+    // multi-GPU halo
+    phys::DevBuf<uint32_t> cross_pairs;
+    uint64_t max_cross_pairs = 0;
+
+    phys_stats stats{};
+    // pinned host mirror of the counters for read-back
+    phys::StepCounters* h_counters = nullptr;
+};

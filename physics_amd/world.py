@@ -1,0 +1,196 @@
+"""World — thin ctypes wrapper over the C ABI (include/physics_hip.h). Every method is one ABI call;
+the reference-shaped object model (PhysicsState / Entity / RigidBody) lives in state.py on top."""
+import ctypes as C
+
+import numpy as np
+
+from . import _abi
+from ._abi import PhysDeviceView, PhysStats, f32p, u32p
+
+
+class PhysError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"physics_hip error {code}: {msg}")
+        self.code = code
+
+
+def _f(a):
+    return None if a is None else np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _p(a, t=f32p):
+    return None if a is None else a.ctypes.data_as(t)
+
+
+class World:
+    def __init__(self, cfg=None):
+        self.lib = _abi.load_library()
+        self.cfg = cfg if cfg is not None else _abi.default_config()
+        self.h = C.c_void_p()
+        self.n = 0
+        self._ck(self.lib.phys_create(C.byref(self.cfg), C.byref(self.h)))
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise PhysError(rc, self.lib.phys_last_error().decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.phys_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # ---- state upload
+    def set_bodies(self, pos, rot=None, lin_vel=None, ang_vel=None, mass=None, inertia=None, shape_type=None,
+                   half_extent=None):
+        pos = _f(pos).reshape(-1, 3)
+        n = pos.shape[0]
+        arrs = [pos, _f(rot), _f(lin_vel), _f(ang_vel), _f(mass), _f(inertia)]
+        for a, w in zip(arrs[1:], (4, 3, 3, 1, 9)):
+            if a is not None and a.size != n * w:
+                raise ValueError("array size does not match the body count")
+        st = None if shape_type is None else np.ascontiguousarray(shape_type, dtype=np.uint32)
+        he = _f(half_extent)
+        self._ck(self.lib.phys_set_bodies(self.h, n, *[_p(a) for a in arrs], _p(st, u32p), _p(he)))
+        self.n = n
+
+    def add_constraint_fix_point(self, body, target):
+        t = _f(target)
+        self._ck(self.lib.phys_add_constraint_fix_point(self.h, body, _p(t)))
+
+    def add_constraint_fix_orientation(self, body, target_rpy):
+        t = _f(target_rpy)
+        self._ck(self.lib.phys_add_constraint_fix_orientation(self.h, body, _p(t)))
+
+    def clear_constraints(self):
+        self._ck(self.lib.phys_clear_constraints(self.h))
+
+    def apply_force_centre_of_gravity(self, body, force):
+        f = _f(force)
+        self._ck(self.lib.phys_apply_force_centre_of_gravity(self.h, body, _p(f)))
+
+    def apply_force_at_position(self, body, force, point):
+        f, p = _f(force), _f(point)
+        self._ck(self.lib.phys_apply_force_at_position(self.h, body, _p(f), _p(p)))
+
+    def apply_force_at_offset(self, body, force, offset):
+        f, o = _f(force), _f(offset)
+        self._ck(self.lib.phys_apply_force_at_offset(self.h, body, _p(f), _p(o)))
+
+    # ---- stepping
+    def apply_gravity(self):
+        self._ck(self.lib.phys_apply_gravity(self.h))
+
+    def step(self, dt_nanos):
+        self._ck(self.lib.phys_step(self.h, dt_nanos))
+
+    def update(self, dt_nanos):
+        self._ck(self.lib.phys_update(self.h, dt_nanos))
+
+    def update_n(self, dt_nanos, n):
+        self._ck(self.lib.phys_update_n(self.h, dt_nanos, n))
+
+    def sync(self):
+        self._ck(self.lib.phys_sync(self.h))
+
+    # ---- read-back
+    def get_transforms(self):
+        pos = np.empty((self.n, 3), np.float32)
+        rot = np.empty((self.n, 4), np.float32)
+        self._ck(self.lib.phys_get_transforms(self.h, _p(pos), _p(rot)))
+        return pos, rot
+
+    def get_velocities(self):
+        lin = np.empty((self.n, 3), np.float32)
+        ang = np.empty((self.n, 3), np.float32)
+        self._ck(self.lib.phys_get_velocities(self.h, _p(lin), _p(ang)))
+        return lin, ang
+
+    def get_forces(self):
+        f = np.empty((self.n, 3), np.float32)
+        t = np.empty((self.n, 3), np.float32)
+        self._ck(self.lib.phys_get_forces(self.h, _p(f), _p(t)))
+        return f, t
+
+    def get_instance_matrices(self):
+        m = np.empty((self.n, 16), np.float32)
+        self._ck(self.lib.phys_get_instance_matrices(self.h, _p(m)))
+        return m
+
+    def get_lambda(self):
+        n = C.c_uint64()
+        self._ck(self.lib.phys_get_lambda(self.h, None, 0, C.byref(n)))
+        out = np.empty(n.value, np.float32)
+        if n.value:
+            self._ck(self.lib.phys_get_lambda(self.h, _p(out), n.value, C.byref(n)))
+        return out
+
+    def get_stats(self):
+        s = PhysStats()
+        self._ck(self.lib.phys_get_stats(self.h, C.byref(s)))
+        return s
+
+    def broadphase(self):
+        n = C.c_uint64()
+        self._ck(self.lib.phys_broadphase(self.h, None, 0, C.byref(n)))
+        out = np.empty((n.value, 2), np.uint32)
+        if n.value:
+            self._ck(self.lib.phys_broadphase(self.h, _p(out, u32p), n.value, C.byref(n)))
+        return out
+
+    def get_aabbs(self):
+        out = np.empty((self.n, 6), np.float32)
+        self._ck(self.lib.phys_get_aabbs(self.h, _p(out)))
+        return out
+
+    def get_manifolds(self):
+        n = C.c_uint64()
+        self._ck(self.lib.phys_get_manifolds(self.h, None, None, None, None, 0, C.byref(n)))
+        m = n.value
+        ids = np.empty((m, 2), np.uint32)
+        counts = np.empty(m, np.uint32)
+        normals = np.empty((m, 3), np.float32)
+        points = np.empty((m, 4, 4), np.float32)
+        if m:
+            self._ck(self.lib.phys_get_manifolds(self.h, _p(ids, u32p), _p(counts, u32p), _p(normals), _p(points), m,
+                                                 C.byref(n)))
+        return ids, counts, normals, points
+
+    def device_view(self):
+        v = PhysDeviceView()
+        self._ck(self.lib.phys_get_device_view(self.h, C.byref(v)))
+        return v
+
+    # ---- sharded broad-phase
+    def set_global_ids(self, ids):
+        ids = np.ascontiguousarray(ids, dtype=np.uint32)
+        self._ck(self.lib.phys_set_global_ids(self.h, _p(ids, u32p)))
+
+    def halo_pack(self, x_lo, x_hi, dev_ptr, cap):
+        n = C.c_uint64()
+        self._ck(self.lib.phys_halo_pack(self.h, x_lo, x_hi, C.c_void_p(dev_ptr), cap, C.byref(n)))
+        return n.value
+
+    def halo_pairs(self, dev_ptr, n_remote):
+        n = C.c_uint64()
+        self._ck(self.lib.phys_halo_pairs(self.h, C.c_void_p(dev_ptr), n_remote, C.byref(n)))
+        return n.value
+
+    def get_cross_pairs(self):
+        n = C.c_uint64()
+        self._ck(self.lib.phys_get_cross_pairs(self.h, None, 0, C.byref(n)))
+        out = np.empty((n.value, 2), np.uint32)
+        if n.value:
+            self._ck(self.lib.phys_get_cross_pairs(self.h, _p(out, u32p), n.value, C.byref(n)))
+        return out
