@@ -94,12 +94,12 @@ int32_t phys_destroy(phys_world* w) {
     DevBuf<float>* fb[] = {&w->pos, &w->rot, &w->lin, &w->ang, &w->force, &w->torque, &w->mass, &w->inv_mass,
                            &w->inv_inertia, &w->half_extent, &w->aabb, &w->cg_x, &w->cg_r, &w->cg_p, &w->cg_ap,
                            &w->cg_rhs, &w->cg_c, &w->cg_scratch, &w->man_normal, &w->man_points, &w->row_normal,
-                           &w->row_data, &w->row_acc};
+                           &w->row_data, &w->row_acc, &w->sorted_box};
     for (auto* b : fb) b->free();
     DevBuf<uint32_t>* ub[] = {&w->shape, &w->global_id, &w->cg_status, &w->cell_xyz, &w->bucket_of, &w->bucket_count,
                               &w->bucket_start, &w->bucket_cursor, &w->sorted_ids, &w->scan_block_sums, &w->pairs,
                               &w->man_a, &w->man_b, &w->man_count, &w->man_color, &w->row_a, &w->row_b, &w->row_count,
-                              &w->row_src, &w->cross_pairs};
+                              &w->row_src, &w->cross_pairs, &w->man_slot};
     for (auto* b : ub) b->free();
     w->pair_keys.free(); w->man_prio.free(); w->body_top.free(); w->body_used.free();
     w->d_constraints.free(); w->counters.free();

@@ -1,0 +1,359 @@
+// broadphase.hip — AABB broad phase for gfx950. No reference counterpart; the
+// result is specified as the SET of pairs (i < j) whose fattened AABBs overlap (include/spec/collide.h).
+//
+// Pipeline per step (all sizes live on the device; nothing returns to the host):
+//   1. k_cell_assign   body -> cell of a uniform grid whose cell edge is the largest AABB extent of the
+//                      step (x1.001), cell -> bucket by 3-D Morton interleave of the low cell bits
+//                      (neighbouring cells = neighbouring buckets = neighbouring memory), count per bucket.
+//   2. exclusive scan  bucket counts -> bucket starts (3 small kernels).
+//   3. k_scatter       bodies grouped by bucket: ids + a bucket-ordered COPY of the AABBs (24 B each), so
+//                      the pair kernel streams candidates instead of gathering them.
+//   4. k_find_pairs    one lane per body (bucket order), half shell of 14 cells; overlap test; hits are
+//                      compacted with wavefront ballot + popcount into a per-wave LDS stage and flushed
+//                      with one global atomic per flush (not per hit) and coalesced 8-byte stores.
+// The emission order is arbitrary; nothing downstream depends on it (DESIGN.md "determinism").
+// Algorithmic bytes: 24 N (each AABB read once) + 8 P (each pair written once).
+#include <algorithm>
+#include <vector>
+
+#include "kernels.hpp"
+
+namespace phys {
+
+constexpr uint32_t kInvalid = 0xFFFFFFFFu;
+
+// ---- Morton bucket of a cell ----------------------------------------------------------------------
+__device__ __forceinline__ uint32_t part1by2(uint32_t x) {  // spread the low 10 bits 3 apart
+    x &= 0x000003ffu;
+    x = (x ^ (x << 16)) & 0xff0000ffu;
+    x = (x ^ (x << 8)) & 0x0300f00fu;
+    x = (x ^ (x << 4)) & 0x030c30c3u;
+    x = (x ^ (x << 2)) & 0x09249249u;
+    return x;
+}
+__device__ __forceinline__ uint32_t bucket_of_cell(int cx, int cy, int cz, uint32_t axis_mask) {
+    return part1by2((uint32_t)cx & axis_mask) | (part1by2((uint32_t)cy & axis_mask) << 1) |
+           (part1by2((uint32_t)cz & axis_mask) << 2);
+}
+__device__ __forceinline__ int cell_coord(float c, float inv_cell) {
+    float t = floorf(c * inv_cell);
+    t = t < -1.0e9f ? -1.0e9f : (t > 1.0e9f ? 1.0e9f : t);
+    return (int)t;
+}
+__device__ __forceinline__ float grid_inv_cell(const StepCounters* ctr) {
+    const float ext = __uint_as_float(ctr->max_extent_bits);
+    const float cell = ext > 0.0f ? ext * 1.001f : 1.0f;
+    return 1.0f / cell;
+}
+
+__global__ __launch_bounds__(256) void k_cell_assign(uint32_t n, const float* __restrict__ aabb,
+                                                     const uint32_t* __restrict__ shape,
+                                                     const StepCounters* __restrict__ ctr, uint32_t axis_mask,
+                                                     uint32_t* __restrict__ bucket_of, uint32_t* __restrict__ rank,
+                                                     uint32_t* __restrict__ bucket_count) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (shape[i] == PHYS_SPEC_SHAPE_NONE) { bucket_of[i] = kInvalid; return; }
+    const float inv_cell = grid_inv_cell(ctr);
+    const float* b = aabb + 6 * (size_t)i;
+    const int cx = cell_coord(0.5f * (b[0] + b[3]), inv_cell);
+    const int cy = cell_coord(0.5f * (b[1] + b[4]), inv_cell);
+    const int cz = cell_coord(0.5f * (b[2] + b[5]), inv_cell);
+    const uint32_t bk = bucket_of_cell(cx, cy, cz, axis_mask);
+    bucket_of[i] = bk;
+    rank[i] = atomicAdd(&bucket_count[bk], 1u);  // order inside a bucket is irrelevant downstream
+}
+
+// ---- exclusive scan of the bucket counts ----------------------------------------------------------
+constexpr int kScanThreads = 256;
+constexpr int kScanItems = 8;
+constexpr int kScanChunk = kScanThreads * kScanItems;
+
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t o = (uint32_t)__shfl_up((int)v, off, 64);
+        if (lane >= off) v += o;
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(kScanThreads) void k_scan_reduce(const uint32_t* __restrict__ in, uint32_t count,
+                                                              uint32_t* __restrict__ block_sums) {
+    __shared__ uint32_t wsum[kScanThreads / 64];
+    const uint32_t base = blockIdx.x * kScanChunk + threadIdx.x * kScanItems;
+    uint32_t s = 0;
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) s += (base + k < count) ? in[base + k] : 0u;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += (uint32_t)__shfl_xor((int)s, off, 64);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t t = 0;
+        for (int k = 0; k < kScanThreads / 64; ++k) t += wsum[k];
+        block_sums[blockIdx.x] = t;
+    }
+}
+
+// one block: exclusive scan of the block sums in place (loops with a carry for long inputs)
+__global__ __launch_bounds__(1024) void k_scan_block_sums(uint32_t* __restrict__ sums, uint32_t count) {
+    __shared__ uint32_t wtot[16];
+    __shared__ uint32_t carry_s;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < count; base += 1024) {
+        const uint32_t idx = base + threadIdx.x;
+        const uint32_t v = idx < count ? sums[idx] : 0u;
+        const uint32_t inc = wave_inclusive_scan(v);
+        if ((threadIdx.x & 63) == 63) wtot[threadIdx.x >> 6] = inc;
+        __syncthreads();
+        uint32_t woff = 0;
+        for (uint32_t k = 0; k < (threadIdx.x >> 6); ++k) woff += wtot[k];
+        const uint32_t carry = carry_s;
+        if (idx < count) sums[idx] = carry + woff + inc - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = carry + woff + inc;
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(kScanThreads) void k_scan_final(const uint32_t* __restrict__ in, uint32_t count,
+                                                             const uint32_t* __restrict__ block_sums,
+                                                             uint32_t* __restrict__ out /*count + 1*/) {
+    __shared__ uint32_t wtot[kScanThreads / 64];
+    const uint32_t base = blockIdx.x * kScanChunk + threadIdx.x * kScanItems;
+    uint32_t v[kScanItems];
+    uint32_t s = 0;
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) { v[k] = (base + k < count) ? in[base + k] : 0u; s += v[k]; }
+    const uint32_t inc = wave_inclusive_scan(s);
+    if ((threadIdx.x & 63) == 63) wtot[threadIdx.x >> 6] = inc;
+    __syncthreads();
+    uint32_t off = block_sums[blockIdx.x];
+    for (uint32_t k = 0; k < (threadIdx.x >> 6); ++k) off += wtot[k];
+    uint32_t run = off + inc - s;
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) {
+        if (base + k < count) out[base + k] = run;
+        run += v[k];
+        if (base + k + 1 == count) out[count] = run;  // grand total in the extra slot
+    }
+}
+
+// ---- group bodies by bucket -----------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_scatter(uint32_t n, const float* __restrict__ aabb,
+                                                 const uint32_t* __restrict__ bucket_of,
+                                                 const uint32_t* __restrict__ rank,
+                                                 const uint32_t* __restrict__ bucket_start,
+                                                 uint32_t* __restrict__ sorted_ids, float* __restrict__ sorted_box) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t bk = bucket_of[i];
+    if (bk == kInvalid) return;
+    const uint32_t s = bucket_start[bk] + rank[i];
+    sorted_ids[s] = i;
+    const float* b = aabb + 6 * (size_t)i;
+    float* o = sorted_box + 6 * (size_t)s;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) o[k] = b[k];
+}
+
+// ---- candidate pairs ------------------------------------------------------------------------------
+constexpr int kPairThreads = 256;
+constexpr int kStagePerWave = 512;  // pairs staged in LDS per wave before a flush (4 KiB)
+
+struct PairStage {
+    uint32_t* lds;    // this wave's LDS segment: kStagePerWave pairs (2 u32 each)
+    uint32_t count;   // wave-uniform
+};
+
+__device__ __forceinline__ void stage_flush(PairStage& st, uint32_t* __restrict__ pairs, uint64_t max_pairs,
+                                            StepCounters* __restrict__ ctr) {
+    const int lane = threadIdx.x & 63;
+    if (st.count == 0) return;
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(&ctr->n_pairs, st.count);
+    base = (uint32_t)__shfl((int)base, 0, 64);
+    if ((uint64_t)base + st.count > max_pairs) {
+        if (lane == 0) atomicOr(&ctr->overflow, 1u);
+    }
+    for (uint32_t k = lane; k < st.count; k += 64) {
+        const uint64_t dst = (uint64_t)base + k;
+        if (dst < max_pairs) {
+            const uint2 pr = reinterpret_cast<const uint2*>(st.lds)[k];
+            reinterpret_cast<uint2*>(pairs)[dst] = pr;
+        }
+    }
+    st.count = 0;
+}
+
+// every lane of the wave calls this together (hit may be false); compacts the hits into the LDS stage
+__device__ __forceinline__ void stage_push(PairStage& st, bool hit, uint32_t a, uint32_t b,
+                                           uint32_t* __restrict__ pairs, uint64_t max_pairs,
+                                           StepCounters* __restrict__ ctr) {
+    const unsigned long long mask = __ballot(hit);
+    if (mask == 0ull) return;
+    const uint32_t hits = (uint32_t)__popcll(mask);
+    if (st.count + hits > (uint32_t)kStagePerWave) stage_flush(st, pairs, max_pairs, ctr);
+    if (hit) {
+        const int lane = threadIdx.x & 63;
+        const uint32_t r = st.count + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+        reinterpret_cast<uint2*>(st.lds)[r] = make_uint2(a, b);
+    }
+    st.count += hits;
+}
+
+__global__ __launch_bounds__(kPairThreads) void k_find_pairs(const uint32_t* __restrict__ bucket_start,
+                                                             uint32_t table_size, uint32_t axis_mask,
+                                                             const uint32_t* __restrict__ sorted_ids,
+                                                             const float* __restrict__ sorted_box,
+                                                             uint32_t* __restrict__ pairs, uint64_t max_pairs,
+                                                             StepCounters* __restrict__ ctr) {
+    __shared__ uint32_t stage[(kPairThreads / 64) * kStagePerWave * 2];
+    PairStage st;
+    st.lds = stage + (threadIdx.x >> 6) * kStagePerWave * 2;
+    st.count = 0;
+    const uint32_t n_active = bucket_start[table_size];
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = s < n_active;
+    const float inv_cell = grid_inv_cell(ctr);
+    uint32_t i = 0;
+    aabb_t bi;
+    int cx = 0, cy = 0, cz = 0;
+    if (live) {
+        i = sorted_ids[s];
+        const float* b = sorted_box + 6 * (size_t)s;
+        bi.lo = v3_make(b[0], b[1], b[2]);
+        bi.hi = v3_make(b[3], b[4], b[5]);
+        cx = cell_coord(0.5f * (bi.lo.x + bi.hi.x), inv_cell);
+        cy = cell_coord(0.5f * (bi.lo.y + bi.hi.y), inv_cell);
+        cz = cell_coord(0.5f * (bi.lo.z + bi.hi.z), inv_cell);
+    }
+    // half shell: own cell + the 13 cells with (dz, dy, dx) > (0, 0, 0) lexicographically
+    for (int c = 0; c < 14; ++c) {
+        int dx, dy, dz;
+        if (c == 0) { dx = 0; dy = 0; dz = 0; }
+        else if (c == 1) { dx = 1; dy = 0; dz = 0; }
+        else if (c < 5) { dx = c - 3; dy = 1; dz = 0; }
+        else { dx = (c - 5) % 3 - 1; dy = ((c - 5) / 3) % 3 - 1; dz = 1; }
+        uint32_t t = 0, t_end = 0;
+        if (live) {
+            const uint32_t bk = bucket_of_cell(cx + dx, cy + dy, cz + dz, axis_mask);
+            t = bucket_start[bk];
+            t_end = bucket_start[bk + 1];
+        }
+        while (__any(t < t_end)) {
+            bool hit = false;
+            uint32_t j = 0;
+            if (t < t_end) {
+                j = sorted_ids[t];
+                const float* b = sorted_box + 6 * (size_t)t;
+                aabb_t bj;
+                bj.lo = v3_make(b[0], b[1], b[2]);
+                bj.hi = v3_make(b[3], b[4], b[5]);
+                // own cell: each unordered pair once by id order. Other cells: a bucket can alias a far cell
+                // (wrap-around); such a candidate fails the overlap test, and the 14 buckets are distinct.
+                hit = aabb_overlap(bi, bj) && (c != 0 || i < j);
+                ++t;
+            }
+            stage_push(st, hit, i < j ? i : j, i < j ? j : i, pairs, max_pairs, ctr);
+        }
+    }
+    stage_flush(st, pairs, max_pairs, ctr);
+}
+
+// ---- host side -------------------------------------------------------------------------------------
+static uint32_t table_size_for(uint64_t n) {
+    uint32_t t = 512;  // 8^3
+    while ((uint64_t)t < 2 * n && t < (1u << 27)) t <<= 3;  // powers of 8: equal Morton bits per axis
+    return t;
+}
+
+int32_t collision_alloc(phys_world* w) {
+    const uint64_t n = w->n;
+    w->max_pairs = w->cfg.max_pairs ? w->cfg.max_pairs : std::max<uint64_t>(24 * n, 4096);
+    w->max_manifolds = w->cfg.max_manifolds ? w->cfg.max_manifolds : std::max<uint64_t>(17 * n, 4096);
+    if (w->max_pairs > 0xFFFFFFF0ull || w->max_manifolds > 0xFFFFFFF0ull) {
+        set_error("max_pairs / max_manifolds exceed u32 indexing");
+        return PHYS_ERR_INVALID_ARG;
+    }
+    w->grid_table_size = table_size_for(n);
+    const uint32_t T = w->grid_table_size;
+    PHYS_HIP_TRY(w->bucket_of.resize(n));
+    PHYS_HIP_TRY(w->bucket_cursor.resize(n));  // rank of each body inside its bucket
+    PHYS_HIP_TRY(w->bucket_count.resize(T));
+    PHYS_HIP_TRY(w->bucket_start.resize((size_t)T + 1));
+    PHYS_HIP_TRY(w->scan_block_sums.resize((T + kScanChunk - 1) / kScanChunk + 1));
+    PHYS_HIP_TRY(w->sorted_ids.resize(n));
+    PHYS_HIP_TRY(w->cell_xyz.resize(0));
+    PHYS_HIP_TRY(w->sorted_box.resize(6 * n));
+    PHYS_HIP_TRY(w->pairs.resize(2 * w->max_pairs));
+    if (!(w->cfg.flags & PHYS_FLAG_BROADPHASE_ONLY)) {
+        const uint64_t M = w->max_manifolds;
+        PHYS_HIP_TRY(w->man_a.resize(M)); PHYS_HIP_TRY(w->man_b.resize(M)); PHYS_HIP_TRY(w->man_count.resize(M));
+        PHYS_HIP_TRY(w->man_color.resize(M)); PHYS_HIP_TRY(w->man_slot.resize(M));
+        PHYS_HIP_TRY(w->man_normal.resize(3 * M)); PHYS_HIP_TRY(w->man_points.resize(16 * M));
+        PHYS_HIP_TRY(w->man_prio.resize(M));
+        PHYS_HIP_TRY(w->body_top.resize(2 * n)); PHYS_HIP_TRY(w->body_used.resize(n));
+        PHYS_HIP_TRY(w->row_src.resize(M));
+        PHYS_HIP_TRY(w->row_a.resize(M)); PHYS_HIP_TRY(w->row_b.resize(M)); PHYS_HIP_TRY(w->row_count.resize(M));
+        PHYS_HIP_TRY(w->row_normal.resize(3 * M));
+        PHYS_HIP_TRY(w->row_data.resize(40 * M));
+        PHYS_HIP_TRY(w->row_acc.resize(12 * M));
+    }
+    return PHYS_OK;
+}
+
+void launch_broadphase(phys_world* w) {
+    const uint32_t n = (uint32_t)w->n;
+    if (n == 0) return;
+    const uint32_t T = w->grid_table_size;
+    uint32_t bits = 0;
+    while ((1u << (3 * bits)) < T) ++bits;
+    const uint32_t axis_mask = (1u << bits) - 1u;
+    hipStream_t s = w->stream;
+    const dim3 gb((n + 255) / 256), tb(256);
+    (void)hipMemsetAsync(w->bucket_count.p, 0, (size_t)T * 4, s);
+    hipLaunchKernelGGL(k_cell_assign, gb, tb, 0, s, n, w->aabb.p, w->shape.p, w->counters.p, axis_mask, w->bucket_of.p,
+                       w->bucket_cursor.p, w->bucket_count.p);
+    const uint32_t nblk = (T + kScanChunk - 1) / kScanChunk;
+    hipLaunchKernelGGL(k_scan_reduce, dim3(nblk), dim3(kScanThreads), 0, s, w->bucket_count.p, T, w->scan_block_sums.p);
+    hipLaunchKernelGGL(k_scan_block_sums, dim3(1), dim3(1024), 0, s, w->scan_block_sums.p, nblk);
+    hipLaunchKernelGGL(k_scan_final, dim3(nblk), dim3(kScanThreads), 0, s, w->bucket_count.p, T, w->scan_block_sums.p,
+                       w->bucket_start.p);
+    hipLaunchKernelGGL(k_scatter, gb, tb, 0, s, n, w->aabb.p, w->bucket_of.p, w->bucket_cursor.p, w->bucket_start.p,
+                       w->sorted_ids.p, w->sorted_box.p);
+    hipLaunchKernelGGL(k_find_pairs, dim3((n + kPairThreads - 1) / kPairThreads), dim3(kPairThreads), 0, s,
+                       w->bucket_start.p, T, axis_mask, w->sorted_ids.p, w->sorted_box.p, w->pairs.p, w->max_pairs,
+                       w->counters.p);
+}
+
+// phys_broadphase read-out: pairs sorted by (i, j). The sort is a host-side convenience of this
+// read-out call; the per-step pipeline never sorts (nothing downstream depends on pair order).
+int32_t sorted_pairs_to_host(phys_world* w, uint32_t* pairs_out, uint64_t cap, uint64_t* n_pairs) {
+    PHYS_HIP_TRY(hipMemcpyAsync(w->h_counters, w->counters.p, sizeof(StepCounters), hipMemcpyDeviceToHost, w->stream));
+    PHYS_HIP_TRY(hipStreamSynchronize(w->stream));
+    if (w->h_counters->overflow & 1u) {
+        set_error("pair capacity exceeded: raise phys_config.max_pairs");
+        return PHYS_ERR_CAPACITY;
+    }
+    const uint64_t m = w->h_counters->n_pairs;
+    *n_pairs = m;
+    if (!pairs_out || m == 0) return PHYS_OK;
+    std::vector<uint64_t> keys(m);
+    {
+        std::vector<uint32_t> raw(2 * m);
+        PHYS_HIP_TRY(hipMemcpy(raw.data(), w->pairs.p, 8 * m, hipMemcpyDeviceToHost));
+        for (uint64_t k = 0; k < m; ++k) keys[k] = ((uint64_t)raw[2 * k] << 32) | raw[2 * k + 1];
+    }
+    std::sort(keys.begin(), keys.end());
+    for (uint64_t k = 0; k < m && k < cap; ++k) {
+        pairs_out[2 * k] = (uint32_t)(keys[k] >> 32);
+        pairs_out[2 * k + 1] = (uint32_t)keys[k];
+    }
+    return PHYS_OK;
+}
+
+}  // namespace phys

@@ -1,0 +1,191 @@
+// solver.hip — sequential-impulse contact solver for gfx950. No reference
+// counterpart; the arithmetic is include/spec/contact_solve.h (solver_prep / solve_manifold).
+//
+// Order of work = the spec's: iterations outermost, colours ascending, manifolds of one colour in
+// parallel (they share no body, so there are no float atomics and the result is independent of the
+// schedule), points of a manifold in index order inside one lane.
+//
+// Data layout: after colouring, manifolds are renumbered colour-major (row d = colour start + slot in
+// colour). Solver rows are plane-major SoA over d, so each of the 8 x n_colours solve launches streams
+// its rows with unit stride; only the body velocities (24 B read + 24 B written per body) and the
+// inverse mass / inertia are gathered by body id.
+// Algorithmic bytes per manifold per iteration: row planes 12 + 12 (ids, count, normal) +
+// per point 40 (rA, rB, masses, bias) + 12 R + 12 W (accumulated impulses), + per body 48 (v, w R+W) +
+// 4 (inv mass) + 36 (inverse inertia).
+#include "kernels.hpp"
+
+namespace phys {
+
+struct ColorTable {
+    uint32_t start[kMaxColors + 1];
+};
+
+constexpr int kRowPlanesPerPoint = 10;  // rA xyz, rB xyz, normal mass, tangent mass 0/1, bias
+constexpr int kAccPlanesPerPoint = 3;   // pn, pt0, pt1
+
+__device__ __forceinline__ v3 ld3s(const float* __restrict__ p, uint32_t i) {
+    return v3_make(p[3 * i], p[3 * i + 1], p[3 * i + 2]);
+}
+__device__ __forceinline__ void st3s(float* __restrict__ p, uint32_t i, v3 v) {
+    p[3 * i] = v.x; p[3 * i + 1] = v.y; p[3 * i + 2] = v.z;
+}
+__device__ __forceinline__ m33 ld_m33(const float* __restrict__ p, uint32_t i) {
+    m33 M;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) M.m[k] = p[9 * (size_t)i + k];
+    return M;
+}
+
+// row index of every manifold: colour-major
+__global__ __launch_bounds__(256) void k_row_src(uint32_t M, ColorTable ct, const uint32_t* __restrict__ man_color,
+                                                 const uint32_t* __restrict__ man_slot, uint32_t* __restrict__ row_src) {
+    const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    row_src[ct.start[man_color[m]] + man_slot[m]] = m;
+}
+
+__global__ __launch_bounds__(256) void k_rows_build(uint32_t M, uint64_t cap, solve_params_t sp,
+                                                    const uint32_t* __restrict__ row_src,
+                                                    const uint32_t* __restrict__ man_a, const uint32_t* __restrict__ man_b,
+                                                    const uint32_t* __restrict__ man_count,
+                                                    const float* __restrict__ man_normal,
+                                                    const float* __restrict__ man_points, const float* __restrict__ pos,
+                                                    const float* __restrict__ inv_mass,
+                                                    const float* __restrict__ inv_inertia, uint32_t* __restrict__ row_a,
+                                                    uint32_t* __restrict__ row_b, uint32_t* __restrict__ row_count,
+                                                    float* __restrict__ row_normal, float* __restrict__ row_data,
+                                                    float* __restrict__ row_acc) {
+    const uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= M) return;
+    const uint32_t m = row_src[d];
+    manifold_t g;
+    const uint32_t a = man_a[m], b = man_b[m];
+    g.count = (int)man_count[m];
+    g.normal = ld3s(man_normal, m);
+    const float4* pp = reinterpret_cast<const float4*>(man_points) + 4 * (size_t)m;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float4 p = pp[k];
+        g.pt[k] = v3_make(p.x, p.y, p.z);
+        g.depth[k] = p.w;
+    }
+    const int has_b = b != PHYS_GROUND_ID;
+    const m33 IA = ld_m33(inv_inertia, a);
+    m33 IB;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) IB.m[k] = 0.0f;
+    float imb = 0.0f;
+    v3 xB = v3_make(0.0f, 0.0f, 0.0f);
+    if (has_b) { IB = ld_m33(inv_inertia, b); imb = inv_mass[b]; xB = ld3s(pos, b); }
+    solver_manifold_t sm;
+    solver_prep(&g, has_b, ld3s(pos, a), xB, inv_mass[a], &IA, imb, &IB, &sp, &sm);
+    row_a[d] = a; row_b[d] = b; row_count[d] = (uint32_t)sm.count;
+    row_normal[0 * cap + d] = sm.n.x; row_normal[1 * cap + d] = sm.n.y; row_normal[2 * cap + d] = sm.n.z;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (k < sm.count) {
+            float* r = row_data + (size_t)(k * kRowPlanesPerPoint) * cap + d;
+            const contact_row_t& c = sm.row[k];
+            r[0 * cap] = c.rA.x; r[1 * cap] = c.rA.y; r[2 * cap] = c.rA.z;
+            r[3 * cap] = c.rB.x; r[4 * cap] = c.rB.y; r[5 * cap] = c.rB.z;
+            r[6 * cap] = c.normal_mass; r[7 * cap] = c.tangent_mass[0]; r[8 * cap] = c.tangent_mass[1];
+            r[9 * cap] = c.bias;
+            float* acc = row_acc + (size_t)(k * kAccPlanesPerPoint) * cap + d;
+            acc[0 * cap] = 0.0f; acc[1 * cap] = 0.0f; acc[2 * cap] = 0.0f;
+        }
+    }
+}
+
+// one colour of one iteration: rows [start, start + count)
+__global__ __launch_bounds__(256) void k_solve_color(uint32_t start, uint32_t count, uint64_t cap, float friction,
+                                                     const uint32_t* __restrict__ row_a, const uint32_t* __restrict__ row_b,
+                                                     const uint32_t* __restrict__ row_count,
+                                                     const float* __restrict__ row_normal,
+                                                     const float* __restrict__ row_data, float* __restrict__ row_acc,
+                                                     const float* __restrict__ inv_mass,
+                                                     const float* __restrict__ inv_inertia, float* __restrict__ lin,
+                                                     float* __restrict__ ang) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= count) return;
+    const uint32_t d = start + t;
+    const uint32_t a = row_a[d], b = row_b[d];
+    solver_manifold_t sm;
+    sm.count = (int)row_count[d];
+    sm.has_b = b != PHYS_GROUND_ID;
+    sm.n = v3_make(row_normal[0 * cap + d], row_normal[1 * cap + d], row_normal[2 * cap + d]);
+    tangent_basis(sm.n, &sm.t1, &sm.t2);  // same inputs as solver_prep => same bits as the stored basis
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        contact_row_t& c = sm.row[k];
+        if (k < sm.count) {
+            const float* r = row_data + (size_t)(k * kRowPlanesPerPoint) * cap + d;
+            c.rA = v3_make(r[0 * cap], r[1 * cap], r[2 * cap]);
+            c.rB = v3_make(r[3 * cap], r[4 * cap], r[5 * cap]);
+            c.normal_mass = r[6 * cap]; c.tangent_mass[0] = r[7 * cap]; c.tangent_mass[1] = r[8 * cap];
+            c.bias = r[9 * cap];
+            const float* acc = row_acc + (size_t)(k * kAccPlanesPerPoint) * cap + d;
+            c.pn = acc[0 * cap]; c.pt[0] = acc[1 * cap]; c.pt[1] = acc[2 * cap];
+        } else {
+            c.rA = v3_make(0.0f, 0.0f, 0.0f); c.rB = v3_make(0.0f, 0.0f, 0.0f);
+            c.normal_mass = 0.0f; c.tangent_mass[0] = 0.0f; c.tangent_mass[1] = 0.0f; c.bias = 0.0f;
+            c.pn = 0.0f; c.pt[0] = 0.0f; c.pt[1] = 0.0f;
+        }
+    }
+    const m33 IA = ld_m33(inv_inertia, a);
+    const float ima = inv_mass[a];
+    v3 vA = ld3s(lin, a), wA = ld3s(ang, a);
+    m33 IB;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) IB.m[k] = 0.0f;
+    float imb = 0.0f;
+    v3 vB = v3_make(0.0f, 0.0f, 0.0f), wB = v3_make(0.0f, 0.0f, 0.0f);
+    if (sm.has_b) { IB = ld_m33(inv_inertia, b); imb = inv_mass[b]; vB = ld3s(lin, b); wB = ld3s(ang, b); }
+    solve_manifold(&sm, friction, ima, &IA, imb, &IB, &vA, &wA, &vB, &wB);
+    st3s(lin, a, vA); st3s(ang, a, wA);
+    if (sm.has_b) { st3s(lin, b, vB); st3s(ang, b, wB); }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (k < sm.count) {
+            float* acc = row_acc + (size_t)(k * kAccPlanesPerPoint) * cap + d;
+            acc[0 * cap] = sm.row[k].pn; acc[1 * cap] = sm.row[k].pt[0]; acc[2 * cap] = sm.row[k].pt[1];
+        }
+    }
+}
+
+// uses the counters fetched by launch_coloring (w->h_counters): manifold and colour counts
+void launch_solver(phys_world* w, float dt) {
+    const StepCounters& c = *w->h_counters;
+    if (c.overflow) return;  // reported by phys_sync / phys_get_stats; never solve a truncated set
+    const uint32_t M = c.n_manifolds;
+    if (M == 0 || w->n == 0) return;
+    const uint32_t ncol = c.n_colors;
+    ColorTable ct;
+    uint32_t run = 0;
+    for (uint32_t k = 0; k <= (uint32_t)kMaxColors; ++k) {
+        ct.start[k] = run;
+        if (k < (uint32_t)kMaxColors) run += (k < ncol) ? c.color_count[k] : 0u;
+    }
+    solve_params_t sp;
+    sp.dt = dt;
+    sp.baumgarte = w->cfg.baumgarte;
+    sp.slop = w->cfg.slop;
+    sp.friction = w->cfg.friction;
+    sp.max_bias = w->cfg.max_bias;
+    hipStream_t s = w->stream;
+    const uint64_t cap = w->max_manifolds;
+    const dim3 gm((M + 255) / 256), tb(256);
+    hipLaunchKernelGGL(k_row_src, gm, tb, 0, s, M, ct, w->man_color.p, w->man_slot.p, w->row_src.p);
+    hipLaunchKernelGGL(k_rows_build, gm, tb, 0, s, M, cap, sp, w->row_src.p, w->man_a.p, w->man_b.p, w->man_count.p,
+                       w->man_normal.p, w->man_points.p, w->pos.p, w->inv_mass.p, w->inv_inertia.p, w->row_a.p,
+                       w->row_b.p, w->row_count.p, w->row_normal.p, w->row_data.p, w->row_acc.p);
+    for (uint32_t it = 0; it < w->cfg.solver_iterations; ++it)
+        for (uint32_t col = 0; col < ncol; ++col) {
+            const uint32_t cnt = c.color_count[col];
+            if (cnt == 0) continue;
+            hipLaunchKernelGGL(k_solve_color, dim3((cnt + 255) / 256), tb, 0, s, ct.start[col], cnt, cap, sp.friction,
+                               w->row_a.p, w->row_b.p, w->row_count.p, w->row_normal.p, w->row_data.p, w->row_acc.p,
+                               w->inv_mass.p, w->inv_inertia.p, w->lin.p, w->ang.p);
+        }
+}
+
+}  // namespace phys

@@ -108,11 +108,12 @@ struct phys_world {
     phys::DevBuf<uint32_t> bucket_of;    // n
     phys::DevBuf<uint32_t> bucket_count, bucket_start, bucket_cursor;  // table
     phys::DevBuf<uint32_t> sorted_ids;   // n: body ids grouped by bucket
+    phys::DevBuf<float> sorted_box;      // 6n: AABBs in bucket order (streamed by the pair kernel)
     phys::DevBuf<uint32_t> scan_block_sums;
     phys::DevBuf<uint32_t> pairs;        // 2 * max_pairs
     phys::DevBuf<uint64_t> pair_keys;    // sort scratch for phys_broadphase
     // manifolds, geometry stage (storage order = emission order, arbitrary)
-    phys::DevBuf<uint32_t> man_a, man_b, man_count, man_color;
+    phys::DevBuf<uint32_t> man_a, man_b, man_count, man_color, man_slot;
     phys::DevBuf<float> man_normal;      // 3 per manifold
     phys::DevBuf<float> man_points;      // 16 per manifold: 4 x (xyz, depth)
     phys::DevBuf<uint64_t> man_prio;
@@ -127,6 +128,7 @@ struct phys_world {
     phys::DevBuf<uint32_t> cross_pairs;
     uint64_t max_cross_pairs = 0;
 
+    uint32_t color_rounds_hint = 8;  // colouring rounds launched before the first completion check
     phys_stats stats{};
     // pinned host mirror of the counters for read-back
     phys::StepCounters* h_counters = nullptr;
