@@ -87,6 +87,11 @@ void RigidBody::step_position(float dt, Trig trig, bool exact_rotation) {
         const float nrm = sqrtf(angular_velocity[0] * angular_velocity[0] +
                                 angular_velocity[1] * angular_velocity[1] +
                                 angular_velocity[2] * angular_velocity[2]);
+        // DELIBERATE DIVERGENCE (Q10): when w != 0 but |w|^2 underflows to 0 the reference
+        // divides by zero in normalize() and the quaternion becomes NaN for good. Contact impulses
+        // produce such w (~1e-27); the rotation update is skipped instead. Unreachable in reference
+        // scenes: apply_gravity adds 14.715*dt to w.x every frame.
+        if (!(nrm > 0.0f)) goto rotation_done;
         float a[3];
         for (int k = 0; k < 3; ++k) a[k] = angular_velocity[k] / nrm;  // normalize()
         const float theta = nrm * dt;                                   // magnitude() * dt
@@ -115,6 +120,7 @@ void RigidBody::step_position(float dt, Trig trig, bool exact_rotation) {
         const float k = aw * bk + ai * bj - aj * bi + ak * bw;
         rotation[0] = i; rotation[1] = j; rotation[2] = k; rotation[3] = w;
     }
+rotation_done:
     // rigid_body.rs:38-39
     for (int k = 0; k < 3; ++k) { force[k] = 0.0f; torque[k] = 0.0f; }
 }

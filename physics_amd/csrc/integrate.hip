@@ -53,6 +53,9 @@ __device__ __forceinline__ void integrate_position(float dt, v3 v, v3 w, v3& x, 
     x.z = x.z + v.z * dt;
     if (w.x != 0.0f || w.y != 0.0f || w.z != 0.0f) {
         const float nrm = v3_norm(w);
+        // Q10: |w|^2 underflowed to 0 although w != 0 (contact impulses leave w ~ 1e-27).
+        // The reference would divide by zero here and poison the quaternion with NaN; skip instead.
+        if (!(nrm > 0.0f)) return;
         const v3 a = v3_div(w, nrm);
         const float theta = nrm * dt;
         const float scale = EXACT_ROT ? theta : det_sinf(theta * 0.5f);  // quirk Q1
