@@ -1,0 +1,255 @@
+#!/usr/bin/env python3
+"""bench.py — throughput of the per-frame rigid-body step (phys_update) on MI355X.
+
+A "step" is one PhysicsState::update over one synthetic scene resident in HBM.
+N = 1 workload: BASELINE.json configs[1] = C2, 10 000 falling cubes + ground contacts, f32. The scene is
+pre-rolled (untimed, part of set-up) until the pile is in contact, so the timed steps carry contacts.
+N > 1: weak scaling; every rank owns one C2-shaped slab placed side by side along x, the broad phase
+exchanges boundary AABBs with one RCCL all-gather per step, narrow phase + solver stay on owned bodies.
+
+Prints ONE JSON line (rank 0). `value` = bodies * steps / seconds over all ranks (whole-job aggregate);
+`steps_per_sec` is the plain reference-style figure. `roofline` describes the dominant kernel of the
+timed workload, timed live with HIP events on the library's own stream (phys_profile_*) in a second,
+separate pass of K steps; `cpu_baseline` is the CPU oracle (a single-threaded C++ restatement; the Rust
+reference cannot be built here) timed on the host cores on a bounded sample of the same trajectory.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s achievable
+
+KERNEL_OF_STAGE = {
+    "step_full": "k_step_full", "velocity_aabb": "k_step_velocity_aabb", "grid": "k_cell_assign+scan+k_scatter",
+    "pairs": "k_find_pairs", "narrow": "k_narrowphase", "color": "k_color_top+k_color_assign",
+    "rows": "k_row_src+k_rows_build", "solve": "k_solve_color", "position": "k_step_position",
+}
+
+
+def stage_bytes(stage, st, iters):
+    """Algorithmic HBM bytes of one STEP spent in `stage` (formulas: DESIGN.md 'algorithmic bytes')."""
+    n, p, m, k = st["n_bodies"], st["n_pairs"], st["n_manifolds"], st["n_contacts"]
+    mb = m - st["n_ground_manifolds"]
+    if stage == "step_full":
+        return 120 * n
+    if stage == "velocity_aabb":
+        return 132 * n
+    if stage == "position":
+        return 80 * n
+    if stage == "grid":
+        return 24 * n + 8 * n + 28 * n  # AABB read, bucket+rank, bucket-ordered copy (ids + boxes)
+    if stage == "pairs":
+        return 24 * n + 8 * p
+    if stage == "narrow":
+        return 96 * p + 44 * st["n_ground_manifolds"] + 100 * m
+    if stage == "color":
+        return 28 * m  # ids + priority + colour + slot, once
+    if stage == "rows":
+        return 100 * m + 24 * m + 76 * k + 52 * (m + mb)
+    if stage == "solve":
+        return iters * (24 * m + 64 * k + 88 * (m + mb))
+    return 0
+
+
+def stats_dict(s):
+    return {f: int(getattr(s, f)) for f in ("n_bodies", "n_pairs", "n_manifolds", "n_contacts", "n_colors",
+                                            "color_rounds", "n_ground_manifolds")}
+
+
+def run_timed(world, steps, dist=None, halo=None):
+    from physics_amd.scenes import DT_NANOS
+    import torch
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    world.sync()
+    t0 = time.perf_counter()
+    if halo is None:
+        world.update_n(DT_NANOS, steps)
+    else:
+        for _ in range(steps):
+            world.update(DT_NANOS)
+            halo.exchange(world)
+    world.sync()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    return time.perf_counter() - t0
+
+
+def profile_pass(world, steps, iters):
+    """K more steps with per-launch HIP events; returns the roofline object of the dominant kernel and
+    the per-stage table."""
+    from physics_amd.scenes import DT_NANOS
+    world.sync()
+    world.profile_enable(True)
+    world.update_n(DT_NANOS, steps)
+    world.sync()
+    prof, psteps = world.profile_get()
+    world.profile_enable(False)
+    st = stats_dict(world.get_stats())
+    table = {}
+    for stage, (ms, launches) in prof.items():
+        table[stage] = {"ms_per_step": ms / max(psteps, 1), "launches_per_step": launches / max(psteps, 1),
+                        "avg_launch_us": 1e3 * ms / max(launches, 1)}
+    kernel_stages = [s for s in table if s in KERNEL_OF_STAGE]
+    dom = max(kernel_stages, key=lambda s: table[s]["ms_per_step"])
+    b_step = stage_bytes(dom, st, iters)
+    launches = table[dom]["launches_per_step"]
+    per_launch = b_step / max(launches, 1e-9)
+    dur_s = table[dom]["avg_launch_us"] * 1e-6
+    achieved = per_launch / dur_s / 1e9 if dur_s > 0 else 0.0
+    total_bytes = sum(stage_bytes(s, st, iters) for s in kernel_stages)
+    roof = {"bound": "hbm", "kernel": KERNEL_OF_STAGE[dom], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+            "algorithmic_bytes_per_launch": int(per_launch), "avg_launch_us": round(table[dom]["avg_launch_us"], 3),
+            "launches_per_step": round(launches, 2), "stage_share_of_device_time": round(
+                table[dom]["ms_per_step"] / max(sum(t["ms_per_step"] for t in table.values()), 1e-12), 3),
+            "algorithmic_bytes_per_step_all_kernels": int(total_bytes)}
+    return roof, table, st
+
+
+def cpu_baseline(scene, preroll, sample_steps):
+    from oracle import binding as ob
+    from physics_amd.scenes import DT_NANOS
+    o = ob.OracleWorld(scene.config(), trig=ob.TRIG_DET)
+    scene.populate(o)
+    o.update_n(DT_NANOS, preroll)
+    t0 = time.perf_counter()
+    o.update_n(DT_NANOS, sample_steps)
+    dt = time.perf_counter() - t0
+    o.close()
+    return {"value": round(scene.n * sample_steps / dt, 1), "unit": "body-steps/s", "cores": 1, "kind": "port",
+            "steps_per_sec": round(sample_steps / dt, 3),
+            "sample": f"oracle (scalar C++ restatement + CPU collision stages, 1 thread; the Rust reference is not "
+                      f"buildable here), same scene, steps {preroll}..{preroll + sample_steps} of the same trajectory"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default="c2", choices=["c1", "c2", "c3", "c5", "t1m", "c4"])
+    ap.add_argument("--preroll", type=int, default=-1, help="untimed set-up steps (default per workload)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the 1M-body target run appended at N=1")
+    args = ap.parse_args()
+
+    import torch
+    import physics_amd
+    from physics_amd import scenes
+    from physics_amd.scenes import DT_NANOS
+
+    world_size = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world_size > 1:
+        import torch.distributed as dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist_mod.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist = dist_mod
+    else:
+        torch.cuda.set_device(local_rank)
+    n_gpus = world_size
+
+    default_preroll = {"c1": 100, "c2": 150, "c3": 150, "c5": 30, "t1m": 100, "c4": 0}
+    preroll = args.preroll if args.preroll >= 0 else default_preroll[args.workload]
+    halo = None
+    if n_gpus == 1:
+        scene = scenes.SCENES[args.workload]()
+    else:
+        from physics_amd import sharding
+        scene, halo = sharding.make_rank_scene(args.workload, rank, world_size, dist, local_rank)
+    world = physics_amd.World(scene.config(device=local_rank))
+    scene.populate(world)
+    if halo is not None:
+        halo.attach(world, scene)
+    iters = scene.solver_iterations
+
+    # set-up (untimed): reach the contact-rich state, then W warm-up steps
+    world.update_n(DT_NANOS, preroll)
+    world.sync()
+    if halo is None:
+        world.update_n(DT_NANOS, args.warmup)
+    else:
+        for _ in range(args.warmup):
+            world.update(DT_NANOS)
+            halo.exchange(world)
+    world.sync()
+
+    elapsed = run_timed(world, args.steps, dist, halo)
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    st = stats_dict(world.get_stats())
+    n_total = scene.n * n_gpus
+    pairs_local = st["n_pairs"] + (halo.last_cross_pairs if halo is not None else 0)
+    if dist is not None:
+        t = torch.tensor([pairs_local], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(t)
+        pairs_total = float(t.item())
+    else:
+        pairs_total = float(pairs_local)
+
+    out = None
+    if rank == 0:
+        roof, table, st2 = profile_pass(world, min(args.steps, 100), iters) if halo is None else (None, None, st)
+        out = {
+            "metric": "rigid_body_steps_per_sec", "value": round(n_total * args.steps / elapsed, 1),
+            "unit": "body-steps/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": scene.name, "n_bodies": n_total, "bodies_per_gpu": scene.n,
+                       "solver_iterations": iters, "dt_nanos": DT_NANOS, "preroll_steps": preroll,
+                       "sharding": "none" if n_gpus == 1 else f"x-slabs x{n_gpus}, halo all-gather per step"},
+            "steps_per_sec": round(args.steps / elapsed, 2),
+            "pairs_per_sec": round(pairs_total * args.steps / elapsed, 1),
+            "scene_stats": st,
+        }
+        if roof is not None:
+            out["roofline"] = roof
+            out["stages"] = {k: {kk: round(vv, 3) for kk, vv in v.items()} for k, v in table.items()}
+    elif halo is None:
+        pass
+    world.close()
+
+    if rank == 0 and n_gpus == 1:
+        if not args.no_cpu_baseline:
+            sample = 200 if args.workload in ("c1", "c2") else 10
+            out["cpu_baseline"] = cpu_baseline(scene, preroll, sample)
+        if not args.no_extra and args.workload == "c2":
+            # north_star target: >= 1M bodies at >= 60 steps/s on one MI355X
+            sc = scenes.target_1m()
+            w = physics_amd.World(sc.config(device=local_rank))
+            sc.populate(w)
+            w.update_n(DT_NANOS, 100)
+            w.sync()
+            k = 60
+            e = run_timed(w, k)
+            roof1, table1, st1 = profile_pass(w, 20, sc.solver_iterations)
+            out["target_1m"] = {"workload": sc.name, "n_bodies": sc.n, "preroll_steps": 100, "steps": k,
+                                "steps_per_sec": round(k / e, 2), "target_steps_per_sec": 60.0,
+                                "body_steps_per_sec": round(sc.n * k / e, 1), "scene_stats": st1, "roofline": roof1,
+                                "stages": {a: {kk: round(vv, 3) for kk, vv in v.items()} for a, v in table1.items()}}
+            w.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -83,7 +83,7 @@ typedef struct phys_stats {
     int32_t cg_converged;   /* 1 = Some(lambda), 0 = None (sle_solver.rs:45) */
     uint64_t steps;         /* updates since creation */
     uint32_t overflow;      /* sticky capacity overflow flags */
-    uint32_t reserved;
+    uint32_t n_ground_manifolds; /* manifolds against the ground plane (subset of n_manifolds) */
 } phys_stats;
 
 /* reference defaults (see phys_config field comments) */
@@ -150,6 +150,28 @@ int32_t phys_get_manifolds(phys_world* w, uint32_t* ids_out /*2*cap*/, uint32_t*
                            float* normals_out /*3*cap*/, float* points_out /*16*cap*/, uint64_t cap,
                            uint64_t* n_manifolds);
 int32_t phys_get_stats(phys_world* w, phys_stats* out);
+
+/* --- per-stage device timing (HIP events on the world's stream), for bench.py's roofline --- */
+#define PHYS_STAGE_STEP_FULL 0u     /* gravity + RigidBody::step, one kernel (no collisions) */
+#define PHYS_STAGE_VELOCITY_AABB 1u /* gravity + velocity half + AABB */
+#define PHYS_STAGE_GRID 2u          /* cell assign, scan, scatter */
+#define PHYS_STAGE_PAIRS 3u         /* k_find_pairs */
+#define PHYS_STAGE_NARROW 4u        /* k_narrowphase */
+#define PHYS_STAGE_COLOR 5u         /* colouring rounds */
+#define PHYS_STAGE_ROWS 6u          /* colour-major renumbering + solver_prep */
+#define PHYS_STAGE_SOLVE 7u         /* k_solve_color */
+#define PHYS_STAGE_POSITION 8u      /* position half */
+#define PHYS_STAGE_CONSTRAINTS 9u   /* constraint assembly + CG (A3-A7) */
+#define PHYS_STAGE_MISC 10u         /* memsets, halo */
+#define PHYS_STAGE_COUNT 12u
+typedef struct phys_profile {
+    double ms[PHYS_STAGE_COUNT];         /* summed device time per stage since enable */
+    uint64_t launches[PHYS_STAGE_COUNT]; /* kernel launches (memsets included) per stage */
+    uint64_t steps;                      /* updates profiled */
+} phys_profile;
+/* on != 0: bracket every launch with events (slower; never inside a timed region). Resets the sums. */
+int32_t phys_profile_enable(phys_world* w, int32_t on);
+int32_t phys_profile_get(phys_world* w, phys_profile* out);
 
 /* --- device-side access for zero-copy callers (torch / RCCL plumbing) and multi-GPU halos --- */
 typedef struct phys_device_view {

@@ -199,6 +199,7 @@ int32_t oracle_get_stats(oracle_world* w, phys_stats* out) {
     out->cg_iterations = w->state.last_cg_iterations;
     out->cg_converged = w->state.last_cg_converged ? 1 : 0;
     out->steps = w->steps;
+    for (const auto& m : w->col.manifolds) out->n_ground_manifolds += (m.b == PHYS_GROUND_ID) ? 1u : 0u;
     return PHYS_OK;
 }
 

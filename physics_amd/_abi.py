@@ -60,8 +60,17 @@ class PhysStats(C.Structure):
         ("cg_converged", C.c_int32),
         ("steps", C.c_uint64),
         ("overflow", C.c_uint32),
-        ("reserved", C.c_uint32),
+        ("n_ground_manifolds", C.c_uint32),
     ]
+
+
+STAGE_COUNT = 12
+STAGE_NAMES = ["step_full", "velocity_aabb", "grid", "pairs", "narrow", "color", "rows", "solve", "position",
+               "constraints", "misc", "unused"]
+
+
+class PhysProfile(C.Structure):
+    _fields_ = [("ms", C.c_double * STAGE_COUNT), ("launches", C.c_uint64 * STAGE_COUNT), ("steps", C.c_uint64)]
 
 
 class PhysDeviceView(C.Structure):
@@ -132,6 +141,8 @@ PROTOTYPES = {
     "phys_get_aabbs": (C.c_int32, [C.c_void_p, f32p]),
     "phys_get_manifolds": (C.c_int32, [C.c_void_p, u32p, u32p, f32p, f32p, C.c_uint64, u64p]),
     "phys_get_stats": (C.c_int32, [C.c_void_p, C.POINTER(PhysStats)]),
+    "phys_profile_enable": (C.c_int32, [C.c_void_p, C.c_int32]),
+    "phys_profile_get": (C.c_int32, [C.c_void_p, C.POINTER(PhysProfile)]),
     "phys_get_device_view": (C.c_int32, [C.c_void_p, C.POINTER(PhysDeviceView)]),
     "phys_set_global_ids": (C.c_int32, [C.c_void_p, u32p]),
     "phys_halo_pack": (C.c_int32, [C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_uint64, u64p]),

@@ -103,6 +103,7 @@ int32_t phys_destroy(phys_world* w) {
     for (auto* b : ub) b->free();
     w->pair_keys.free(); w->man_prio.free(); w->body_top.free(); w->body_used.free();
     w->d_constraints.free(); w->counters.free();
+    w->prof.destroy();
     if (w->h_counters) (void)hipHostFree(w->h_counters);
     if (w->stream) (void)hipStreamDestroy(w->stream);
     delete w;
@@ -249,7 +250,7 @@ static int32_t enqueue_update(phys_world* w, float dt) {
     if (!collisions) {
         launch_step_full(w, dt, gravity_pending);
     } else {
-        PHYS_HIP_TRY(hipMemsetAsync(w->counters.p, 0, sizeof(StepCounters), w->stream));
+        { PHYS_PROF(w, PHYS_STAGE_MISC); PHYS_HIP_TRY(hipMemsetAsync(w->counters.p, 0, sizeof(StepCounters), w->stream)); }
         launch_step_velocity_aabb(w, dt, gravity_pending);
         launch_broadphase(w);
         if (!(w->cfg.flags & PHYS_FLAG_BROADPHASE_ONLY)) {
@@ -261,6 +262,7 @@ static int32_t enqueue_update(phys_world* w, float dt) {
     }
     PHYS_HIP_TRY(hipGetLastError());
     w->steps++;
+    if (w->prof.on) { w->prof.steps++; if (w->prof.used > 4096) w->prof.collect(w->stream); }
     return PHYS_OK;
 }
 
@@ -420,6 +422,24 @@ int32_t phys_get_stats(phys_world* w, phys_stats* out) {
     }
     out->steps = w->steps;
     out->overflow = c.overflow;
+    out->n_ground_manifolds = c.n_ground_manifolds;
+    return PHYS_OK;
+}
+
+int32_t phys_profile_enable(phys_world* w, int32_t on) {
+    ENTER(w);
+    PHYS_HIP_TRY(hipStreamSynchronize(w->stream));
+    w->prof.reset();
+    w->prof.on = on != 0;
+    return PHYS_OK;
+}
+
+int32_t phys_profile_get(phys_world* w, phys_profile* out) {
+    ENTER(w);
+    if (!out) return fail(PHYS_ERR_INVALID_ARG, "null output");
+    w->prof.collect(w->stream);
+    for (uint32_t k = 0; k < PHYS_STAGE_COUNT; ++k) { out->ms[k] = w->prof.ms[k]; out->launches[k] = w->prof.launches[k]; }
+    out->steps = w->prof.steps;
     return PHYS_OK;
 }
 

@@ -315,19 +315,19 @@ void launch_broadphase(phys_world* w) {
     const uint32_t axis_mask = (1u << bits) - 1u;
     hipStream_t s = w->stream;
     const dim3 gb((n + 255) / 256), tb(256);
-    (void)hipMemsetAsync(w->bucket_count.p, 0, (size_t)T * 4, s);
-    hipLaunchKernelGGL(k_cell_assign, gb, tb, 0, s, n, w->aabb.p, w->shape.p, w->counters.p, axis_mask, w->bucket_of.p,
-                       w->bucket_cursor.p, w->bucket_count.p);
+    { PHYS_PROF(w, PHYS_STAGE_GRID); (void)hipMemsetAsync(w->bucket_count.p, 0, (size_t)T * 4, s); }
+    { PHYS_PROF(w, PHYS_STAGE_GRID); hipLaunchKernelGGL(k_cell_assign, gb, tb, 0, s, n, w->aabb.p, w->shape.p, w->counters.p, axis_mask, w->bucket_of.p,
+                       w->bucket_cursor.p, w->bucket_count.p); }
     const uint32_t nblk = (T + kScanChunk - 1) / kScanChunk;
-    hipLaunchKernelGGL(k_scan_reduce, dim3(nblk), dim3(kScanThreads), 0, s, w->bucket_count.p, T, w->scan_block_sums.p);
-    hipLaunchKernelGGL(k_scan_block_sums, dim3(1), dim3(1024), 0, s, w->scan_block_sums.p, nblk);
-    hipLaunchKernelGGL(k_scan_final, dim3(nblk), dim3(kScanThreads), 0, s, w->bucket_count.p, T, w->scan_block_sums.p,
-                       w->bucket_start.p);
-    hipLaunchKernelGGL(k_scatter, gb, tb, 0, s, n, w->aabb.p, w->bucket_of.p, w->bucket_cursor.p, w->bucket_start.p,
-                       w->sorted_ids.p, w->sorted_box.p);
-    hipLaunchKernelGGL(k_find_pairs, dim3((n + kPairThreads - 1) / kPairThreads), dim3(kPairThreads), 0, s,
+    { PHYS_PROF(w, PHYS_STAGE_GRID); hipLaunchKernelGGL(k_scan_reduce, dim3(nblk), dim3(kScanThreads), 0, s, w->bucket_count.p, T, w->scan_block_sums.p); }
+    { PHYS_PROF(w, PHYS_STAGE_GRID); hipLaunchKernelGGL(k_scan_block_sums, dim3(1), dim3(1024), 0, s, w->scan_block_sums.p, nblk); }
+    { PHYS_PROF(w, PHYS_STAGE_GRID); hipLaunchKernelGGL(k_scan_final, dim3(nblk), dim3(kScanThreads), 0, s, w->bucket_count.p, T, w->scan_block_sums.p,
+                       w->bucket_start.p); }
+    { PHYS_PROF(w, PHYS_STAGE_GRID); hipLaunchKernelGGL(k_scatter, gb, tb, 0, s, n, w->aabb.p, w->bucket_of.p, w->bucket_cursor.p, w->bucket_start.p,
+                       w->sorted_ids.p, w->sorted_box.p); }
+    { PHYS_PROF(w, PHYS_STAGE_PAIRS); hipLaunchKernelGGL(k_find_pairs, dim3((n + kPairThreads - 1) / kPairThreads), dim3(kPairThreads), 0, s,
                        w->bucket_start.p, T, axis_mask, w->sorted_ids.p, w->sorted_box.p, w->pairs.p, w->max_pairs,
-                       w->counters.p);
+                       w->counters.p); }
 }
 
 // phys_broadphase read-out: pairs sorted by (i, j). The sort is a host-side convenience of this

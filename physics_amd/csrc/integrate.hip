@@ -252,6 +252,7 @@ static void launch_full(phys_world* w, const StepParams& sp) {
 #define LAUNCH(D, E)                                                                                              \
     hipLaunchKernelGGL((k_step_full<FORCES, GRAVITY, D, E>), g, b, 0, w->stream, sp, w->pos.p, w->rot.p, w->lin.p, \
                        w->ang.p, w->force.p, w->torque.p, w->mass.p, w->inv_inertia.p)
+    PHYS_PROF(w, PHYS_STAGE_STEP_FULL);
     if (diag && exact) LAUNCH(true, true);
     else if (diag) LAUNCH(true, false);
     else if (exact) LAUNCH(false, true);
@@ -279,6 +280,7 @@ void launch_step_velocity_aabb(phys_world* w, float dt, bool gravity) {
                        w->ang.p, w->force.p, w->torque.p, w->mass.p, w->inv_inertia.p, w->shape.p,                \
                        w->half_extent.p, margin, w->aabb.p, w->counters.p)
     const int sel = (w->forces_dirty ? 4 : 0) | (gravity ? 2 : 0) | (diag ? 1 : 0);
+    PHYS_PROF(w, PHYS_STAGE_VELOCITY_AABB);
     switch (sel) {
         case 0: LAUNCH(false, false, false); break;
         case 1: LAUNCH(false, false, true); break;
@@ -296,6 +298,7 @@ void launch_step_velocity_aabb(phys_world* w, float dt, bool gravity) {
 
 void launch_aabb_only(phys_world* w) {
     if (w->n == 0) return;
+    PHYS_PROF(w, PHYS_STAGE_VELOCITY_AABB);
     hipLaunchKernelGGL(k_aabb_only, grid_for(w->n), dim3(256), 0, w->stream, (uint32_t)w->n, w->pos.p, w->rot.p,
                        w->shape.p, w->half_extent.p, w->cfg.contact_margin, w->aabb.p, w->counters.p);
     w->aabbs_valid = true;
@@ -304,6 +307,7 @@ void launch_aabb_only(phys_world* w) {
 void launch_step_position(phys_world* w, float dt) {
     if (w->n == 0) return;
     const dim3 g = grid_for(w->n), b(256);
+    PHYS_PROF(w, PHYS_STAGE_POSITION);
     if (w->cfg.flags & PHYS_FLAG_EXACT_ROTATION)
         hipLaunchKernelGGL((k_step_position<true>), g, b, 0, w->stream, (uint32_t)w->n, dt, w->pos.p, w->rot.p, w->lin.p, w->ang.p);
     else

@@ -11,6 +11,10 @@
 
 static_assert(PHYS_MAX_COLORS == phys::kMaxColors, "colour limit mismatch");
 
+#define PHYS_PROF_CAT2(a, b) a##b
+#define PHYS_PROF_CAT(a, b) PHYS_PROF_CAT2(a, b)
+#define PHYS_PROF(w, st) phys::ProfScope PHYS_PROF_CAT(_prof_scope_, __LINE__)((w)->prof, (w)->stream, (st))
+
 namespace phys {
 
 // integrate.hip

@@ -82,6 +82,8 @@ __global__ __launch_bounds__(kNpThreads) void k_narrowphase(
             block_base = bb;
         }
         if (lane == 0 && pts) atomicAdd(&ctr->n_contacts, pts);
+        const unsigned long long gmask = __ballot(has && b == PHYS_GROUND_ID);
+        if (lane == 0 && gmask) atomicAdd(&ctr->n_ground_manifolds, (uint32_t)__popcll(gmask));
         __syncthreads();
         if (has) {
             uint32_t woff = 0;
@@ -201,19 +203,19 @@ void launch_narrowphase(phys_world* w) {
     const uint64_t work = (uint64_t)n_ground + w->max_pairs;
     uint64_t blocks = (work + kNpThreads - 1) / kNpThreads;
     if (blocks > 256 * 16) blocks = 256 * 16;
-    hipLaunchKernelGGL(k_narrowphase, dim3((unsigned)blocks), dim3(kNpThreads), 0, w->stream, n_ground, w->pairs.p,
+    { PHYS_PROF(w, PHYS_STAGE_NARROW); hipLaunchKernelGGL(k_narrowphase, dim3((unsigned)blocks), dim3(kNpThreads), 0, w->stream, n_ground, w->pairs.p,
                        w->max_pairs, w->pos.p, w->rot.p, w->half_extent.p, w->shape.p, w->cfg.contact_margin,
                        w->cfg.ground_height, w->max_manifolds, w->man_a.p, w->man_b.p, w->man_count.p, w->man_color.p,
-                       w->man_normal.p, w->man_points.p, w->man_prio.p, w->counters.p);
+                       w->man_normal.p, w->man_points.p, w->man_prio.p, w->counters.p); }
 }
 
 static void launch_color_round(phys_world* w, uint32_t round, unsigned blocks) {
     unsigned long long* top = w->body_top.p + (round & 1u) * w->n;
     unsigned long long* top_next = w->body_top.p + ((round + 1u) & 1u) * w->n;
-    hipLaunchKernelGGL(k_color_top, dim3(blocks), dim3(256), 0, w->stream, w->max_manifolds, w->man_a.p, w->man_b.p,
-                       w->man_color.p, w->man_prio.p, top, w->counters.p);
-    hipLaunchKernelGGL(k_color_assign, dim3(blocks), dim3(256), 0, w->stream, w->max_manifolds, w->man_a.p, w->man_b.p,
-                       w->man_color.p, w->man_slot.p, w->man_prio.p, top, top_next, w->body_used.p, w->counters.p);
+    { PHYS_PROF(w, PHYS_STAGE_COLOR); hipLaunchKernelGGL(k_color_top, dim3(blocks), dim3(256), 0, w->stream, w->max_manifolds, w->man_a.p, w->man_b.p,
+                       w->man_color.p, w->man_prio.p, top, w->counters.p); }
+    { PHYS_PROF(w, PHYS_STAGE_COLOR); hipLaunchKernelGGL(k_color_assign, dim3(blocks), dim3(256), 0, w->stream, w->max_manifolds, w->man_a.p, w->man_b.p,
+                       w->man_color.p, w->man_slot.p, w->man_prio.p, top, top_next, w->body_used.p, w->counters.p); }
 }
 
 // Runs colouring rounds until the device reports no uncoloured manifold, then leaves the final counters
@@ -222,8 +224,8 @@ void launch_coloring(phys_world* w) {
     const uint64_t n = w->n;
     if (n == 0) return;
     hipStream_t s = w->stream;
-    (void)hipMemsetAsync(w->body_used.p, 0, n * 8, s);
-    (void)hipMemsetAsync(w->body_top.p, 0, 2 * n * 8, s);
+    { PHYS_PROF(w, PHYS_STAGE_COLOR); (void)hipMemsetAsync(w->body_used.p, 0, n * 8, s); }
+    { PHYS_PROF(w, PHYS_STAGE_COLOR); (void)hipMemsetAsync(w->body_top.p, 0, 2 * n * 8, s); }
     uint64_t blocks64 = (w->max_manifolds + 255) / 256;
     if (blocks64 > 256 * 8) blocks64 = 256 * 8;
     const unsigned blocks = (unsigned)blocks64;
@@ -233,6 +235,7 @@ void launch_coloring(phys_world* w) {
         for (uint32_t k = 0; k < batch; ++k) launch_color_round(w, round++, blocks);
         (void)hipMemcpyAsync(w->h_counters, w->counters.p, sizeof(StepCounters), hipMemcpyDeviceToHost, s);
         (void)hipStreamSynchronize(s);
+        if (w->prof.on) w->prof.collect(s);
         if (w->h_counters->n_uncolored == 0 || w->h_counters->overflow) break;
         batch = 2;
     }

@@ -174,17 +174,17 @@ void launch_solver(phys_world* w, float dt) {
     hipStream_t s = w->stream;
     const uint64_t cap = w->max_manifolds;
     const dim3 gm((M + 255) / 256), tb(256);
-    hipLaunchKernelGGL(k_row_src, gm, tb, 0, s, M, ct, w->man_color.p, w->man_slot.p, w->row_src.p);
-    hipLaunchKernelGGL(k_rows_build, gm, tb, 0, s, M, cap, sp, w->row_src.p, w->man_a.p, w->man_b.p, w->man_count.p,
+    { PHYS_PROF(w, PHYS_STAGE_ROWS); hipLaunchKernelGGL(k_row_src, gm, tb, 0, s, M, ct, w->man_color.p, w->man_slot.p, w->row_src.p); }
+    { PHYS_PROF(w, PHYS_STAGE_ROWS); hipLaunchKernelGGL(k_rows_build, gm, tb, 0, s, M, cap, sp, w->row_src.p, w->man_a.p, w->man_b.p, w->man_count.p,
                        w->man_normal.p, w->man_points.p, w->pos.p, w->inv_mass.p, w->inv_inertia.p, w->row_a.p,
-                       w->row_b.p, w->row_count.p, w->row_normal.p, w->row_data.p, w->row_acc.p);
+                       w->row_b.p, w->row_count.p, w->row_normal.p, w->row_data.p, w->row_acc.p); }
     for (uint32_t it = 0; it < w->cfg.solver_iterations; ++it)
         for (uint32_t col = 0; col < ncol; ++col) {
             const uint32_t cnt = c.color_count[col];
             if (cnt == 0) continue;
-            hipLaunchKernelGGL(k_solve_color, dim3((cnt + 255) / 256), tb, 0, s, ct.start[col], cnt, cap, sp.friction,
+            { PHYS_PROF(w, PHYS_STAGE_SOLVE); hipLaunchKernelGGL(k_solve_color, dim3((cnt + 255) / 256), tb, 0, s, ct.start[col], cnt, cap, sp.friction,
                                w->row_a.p, w->row_b.p, w->row_count.p, w->row_normal.p, w->row_data.p, w->row_acc.p,
-                               w->inv_mass.p, w->inv_inertia.p, w->lin.p, w->ang.p);
+                               w->inv_mass.p, w->inv_inertia.p, w->lin.p, w->ang.p); }
         }
 }
 

@@ -61,9 +61,48 @@ struct StepCounters {
     uint32_t max_extent_bits;  // float bits of the largest AABB extent (positive floats order as uints)
     uint32_t n_halo;         // halo records packed
     uint32_t n_cross_pairs;
+    uint32_t n_ground_manifolds;
     uint32_t color_count[kMaxColors];  // manifolds per colour
     uint32_t color_start[kMaxColors + 1];
     uint32_t color_cursor[kMaxColors];
+};
+
+// per-stage device timing with HIP events on the world's stream (phys_profile_enable)
+struct Profiler {
+    bool on = false;
+    std::vector<hipEvent_t> ev;      // pairs: [2k] start, [2k+1] stop
+    std::vector<uint32_t> stage;     // stage of pair k
+    size_t used = 0;                 // pairs in flight
+    double ms[PHYS_STAGE_COUNT] = {};
+    uint64_t launches[PHYS_STAGE_COUNT] = {};
+    uint64_t steps = 0;
+    void begin(hipStream_t s, uint32_t st) {
+        if (2 * used + 2 > ev.size()) {
+            hipEvent_t a, b;
+            (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+            ev.push_back(a); ev.push_back(b); stage.push_back(0);
+        }
+        stage[used] = st;
+        (void)hipEventRecord(ev[2 * used], s);
+    }
+    void end(hipStream_t s) { (void)hipEventRecord(ev[2 * used + 1], s); ++used; }
+    void collect(hipStream_t s) {  // the stream must be idle or is synchronised here
+        if (!used) return;
+        (void)hipStreamSynchronize(s);
+        for (size_t k = 0; k < used; ++k) {
+            float t = 0.0f;
+            if (hipEventElapsedTime(&t, ev[2 * k], ev[2 * k + 1]) == hipSuccess) { ms[stage[k]] += t; launches[stage[k]] += 1; }
+        }
+        used = 0;
+    }
+    void reset() { for (auto& m : ms) m = 0; for (auto& l : launches) l = 0; steps = 0; used = 0; }
+    void destroy() { for (auto e : ev) (void)hipEventDestroy(e); ev.clear(); stage.clear(); used = 0; }
+};
+
+struct ProfScope {
+    Profiler& p; hipStream_t s;
+    ProfScope(Profiler& p_, hipStream_t s_, uint32_t st) : p(p_), s(s_) { if (p.on) p.begin(s, st); }
+    ~ProfScope() { if (p.on) p.end(s); }
 };
 
 struct Constraint {
@@ -129,6 +168,7 @@ struct phys_world {
     uint64_t max_cross_pairs = 0;
 
     uint32_t color_rounds_hint = 8;  // colouring rounds launched before the first completion check
+    phys::Profiler prof;
     phys_stats stats{};
     // pinned host mirror of the counters for read-back
     phys::StepCounters* h_counters = nullptr;

@@ -5,7 +5,7 @@ import ctypes as C
 import numpy as np
 
 from . import _abi
-from ._abi import PhysDeviceView, PhysStats, f32p, u32p
+from ._abi import STAGE_NAMES, PhysDeviceView, PhysProfile, PhysStats, f32p, u32p
 
 
 class PhysError(RuntimeError):
@@ -166,6 +166,15 @@ class World:
             self._ck(self.lib.phys_get_manifolds(self.h, _p(ids, u32p), _p(counts, u32p), _p(normals), _p(points), m,
                                                  C.byref(n)))
         return ids, counts, normals, points
+
+    def profile_enable(self, on=True):
+        self._ck(self.lib.phys_profile_enable(self.h, int(on)))
+
+    def profile_get(self):
+        """{stage: (device ms summed, launches)} and the number of profiled updates."""
+        p = PhysProfile()
+        self._ck(self.lib.phys_profile_get(self.h, C.byref(p)))
+        return {STAGE_NAMES[k]: (p.ms[k], p.launches[k]) for k in range(len(STAGE_NAMES)) if p.launches[k]}, p.steps
 
     def device_view(self):
         v = PhysDeviceView()
