@@ -99,7 +99,7 @@ int32_t phys_destroy(phys_world* w) {
     DevBuf<uint32_t>* ub[] = {&w->shape, &w->global_id, &w->cg_status, &w->cell_xyz, &w->bucket_of, &w->bucket_count,
                               &w->bucket_start, &w->bucket_cursor, &w->sorted_ids, &w->scan_block_sums, &w->pairs,
                               &w->man_a, &w->man_b, &w->man_count, &w->man_color, &w->row_a, &w->row_b, &w->row_count,
-                              &w->row_src, &w->cross_pairs, &w->man_slot};
+                              &w->row_src, &w->cross_pairs, &w->man_slot, &w->color_block_hist};
     for (auto* b : ub) b->free();
     w->pair_keys.free(); w->man_prio.free(); w->body_top.free(); w->body_used.free();
     w->d_constraints.free(); w->counters.free();

@@ -55,10 +55,10 @@ __global__ __launch_bounds__(256) void k_cell_assign(uint32_t n, const float* __
     if (i >= n) return;
     if (shape[i] == PHYS_SPEC_SHAPE_NONE) { bucket_of[i] = kInvalid; return; }
     const float inv_cell = grid_inv_cell(ctr);
-    const float* b = aabb + 6 * (size_t)i;
-    const int cx = cell_coord(0.5f * (b[0] + b[3]), inv_cell);
-    const int cy = cell_coord(0.5f * (b[1] + b[4]), inv_cell);
-    const int cz = cell_coord(0.5f * (b[2] + b[5]), inv_cell);
+    const v3 lo = ld3(aabb, 2 * i), hi = ld3(aabb, 2 * i + 1);
+    const int cx = cell_coord(0.5f * (lo.x + hi.x), inv_cell);
+    const int cy = cell_coord(0.5f * (lo.y + hi.y), inv_cell);
+    const int cz = cell_coord(0.5f * (lo.z + hi.z), inv_cell);
     const uint32_t bk = bucket_of_cell(cx, cy, cz, axis_mask);
     bucket_of[i] = bk;
     rank[i] = atomicAdd(&bucket_count[bk], 1u);  // order inside a bucket is irrelevant downstream
@@ -154,10 +154,8 @@ __global__ __launch_bounds__(256) void k_scatter(uint32_t n, const float* __rest
     if (bk == kInvalid) return;
     const uint32_t s = bucket_start[bk] + rank[i];
     sorted_ids[s] = i;
-    const float* b = aabb + 6 * (size_t)i;
-    float* o = sorted_box + 6 * (size_t)s;
-#pragma unroll
-    for (int k = 0; k < 6; ++k) o[k] = b[k];
+    st3(sorted_box, 2 * s, ld3(aabb, 2 * i));
+    st3(sorted_box, 2 * s + 1, ld3(aabb, 2 * i + 1));
 }
 
 // ---- candidate pairs ------------------------------------------------------------------------------
@@ -224,9 +222,8 @@ __global__ __launch_bounds__(kPairThreads) void k_find_pairs(const uint32_t* __r
     int cx = 0, cy = 0, cz = 0;
     if (live) {
         i = sorted_ids[s];
-        const float* b = sorted_box + 6 * (size_t)s;
-        bi.lo = v3_make(b[0], b[1], b[2]);
-        bi.hi = v3_make(b[3], b[4], b[5]);
+        bi.lo = ld3(sorted_box, 2 * s);
+        bi.hi = ld3(sorted_box, 2 * s + 1);
         cx = cell_coord(0.5f * (bi.lo.x + bi.hi.x), inv_cell);
         cy = cell_coord(0.5f * (bi.lo.y + bi.hi.y), inv_cell);
         cz = cell_coord(0.5f * (bi.lo.z + bi.hi.z), inv_cell);
@@ -249,10 +246,9 @@ __global__ __launch_bounds__(kPairThreads) void k_find_pairs(const uint32_t* __r
             uint32_t j = 0;
             if (t < t_end) {
                 j = sorted_ids[t];
-                const float* b = sorted_box + 6 * (size_t)t;
                 aabb_t bj;
-                bj.lo = v3_make(b[0], b[1], b[2]);
-                bj.hi = v3_make(b[3], b[4], b[5]);
+                bj.lo = ld3(sorted_box, 2 * t);
+                bj.hi = ld3(sorted_box, 2 * t + 1);
                 // own cell: each unordered pair once by id order. Other cells: a bucket can alias a far cell
                 // (wrap-around); such a candidate fails the overlap test, and the 14 buckets are distinct.
                 hit = aabb_overlap(bi, bj) && (c != 0 || i < j);
@@ -298,6 +294,7 @@ int32_t collision_alloc(phys_world* w) {
         PHYS_HIP_TRY(w->man_prio.resize(M));
         PHYS_HIP_TRY(w->body_top.resize(2 * n)); PHYS_HIP_TRY(w->body_used.resize(n));
         PHYS_HIP_TRY(w->row_src.resize(M));
+        PHYS_HIP_TRY(w->color_block_hist.resize((size_t)kMaxColors * 512));
         PHYS_HIP_TRY(w->row_a.resize(M)); PHYS_HIP_TRY(w->row_b.resize(M)); PHYS_HIP_TRY(w->row_count.resize(M));
         PHYS_HIP_TRY(w->row_normal.resize(3 * M));
         PHYS_HIP_TRY(w->row_data.resize(40 * M));

@@ -17,12 +17,6 @@ struct StepParams {
     float g_torque[3];  // offset x force (rigid_body.rs:60), same for every body
 };
 
-__device__ __forceinline__ v3 ld3(const float* __restrict__ p, uint32_t i) {
-    return v3_make(p[3 * i], p[3 * i + 1], p[3 * i + 2]);
-}
-__device__ __forceinline__ void st3(float* __restrict__ p, uint32_t i, v3 v) {
-    p[3 * i] = v.x; p[3 * i + 1] = v.y; p[3 * i + 2] = v.z;
-}
 
 // velocity half of RigidBody::step: rigid_body.rs:27, 30-31
 template <bool DIAG>
@@ -131,8 +125,8 @@ __global__ __launch_bounds__(256) void k_step_velocity_aabb(StepParams sp, const
         quat q; q.i = qq.x; q.j = qq.y; q.k = qq.z; q.w = qq.w;
         const uint32_t type = shape[i];
         const aabb_t b = body_aabb(x, q, ld3(half_extent, i), type, margin);
-        aabb[6 * i + 0] = b.lo.x; aabb[6 * i + 1] = b.lo.y; aabb[6 * i + 2] = b.lo.z;
-        aabb[6 * i + 3] = b.hi.x; aabb[6 * i + 4] = b.hi.y; aabb[6 * i + 5] = b.hi.z;
+        st3(aabb, 2 * i, b.lo);
+        st3(aabb, 2 * i + 1, b.hi);
         if (type != PHYS_SPEC_SHAPE_NONE)
             ext = det_maxf(b.hi.x - b.lo.x, det_maxf(b.hi.y - b.lo.y, b.hi.z - b.lo.z));
     }
@@ -143,7 +137,9 @@ __global__ __launch_bounds__(256) void k_step_velocity_aabb(StepParams sp, const
         const uint32_t o = (uint32_t)__shfl_xor((int)bits, off, 64);
         bits = o > bits ? o : bits;
     }
-    if ((threadIdx.x & 63) == 0 && bits != 0) atomicMax(&ctr->max_extent_bits, bits);
+    // one same-address atomic per wave would serialise the whole launch (~88 atomics/us on one word):
+    // only waves that can still raise the maximum issue it (the plain read may be stale-low, never wrong)
+    if ((threadIdx.x & 63) == 0 && bits > ctr->max_extent_bits) atomicMax(&ctr->max_extent_bits, bits);
 }
 
 // AABBs only (phys_broadphase / phys_get_aabbs on the current poses)
@@ -159,8 +155,8 @@ __global__ __launch_bounds__(256) void k_aabb_only(uint32_t n, const float* __re
         quat q; q.i = qq.x; q.j = qq.y; q.k = qq.z; q.w = qq.w;
         const uint32_t type = shape[i];
         const aabb_t b = body_aabb(x, q, ld3(half_extent, i), type, margin);
-        aabb[6 * i + 0] = b.lo.x; aabb[6 * i + 1] = b.lo.y; aabb[6 * i + 2] = b.lo.z;
-        aabb[6 * i + 3] = b.hi.x; aabb[6 * i + 4] = b.hi.y; aabb[6 * i + 5] = b.hi.z;
+        st3(aabb, 2 * i, b.lo);
+        st3(aabb, 2 * i + 1, b.hi);
         if (type != PHYS_SPEC_SHAPE_NONE)
             ext = det_maxf(b.hi.x - b.lo.x, det_maxf(b.hi.y - b.lo.y, b.hi.z - b.lo.z));
     }
@@ -170,7 +166,9 @@ __global__ __launch_bounds__(256) void k_aabb_only(uint32_t n, const float* __re
         const uint32_t o = (uint32_t)__shfl_xor((int)bits, off, 64);
         bits = o > bits ? o : bits;
     }
-    if ((threadIdx.x & 63) == 0 && bits != 0) atomicMax(&ctr->max_extent_bits, bits);
+    // one same-address atomic per wave would serialise the whole launch (~88 atomics/us on one word):
+    // only waves that can still raise the maximum issue it (the plain read may be stale-low, never wrong)
+    if ((threadIdx.x & 63) == 0 && bits > ctr->max_extent_bits) atomicMax(&ctr->max_extent_bits, bits);
 }
 
 // collision mode, second half: position + rotation update

@@ -17,6 +17,19 @@ static_assert(PHYS_MAX_COLORS == phys::kMaxColors, "colour limit mismatch");
 
 namespace phys {
 
+// 12-byte packed attribute access as ONE dwordx3 memory instruction per lane (a wave then covers one
+// contiguous 768-B span). Written as three scalar accesses hipcc emits three dword instructions, each
+// touching every line of the span again.
+struct alignas(4) packed3 { float x, y, z; };
+__device__ __forceinline__ v3 ld3(const float* __restrict__ p, uint32_t i) {
+    const packed3 t = reinterpret_cast<const packed3*>(p)[i];
+    return v3_make(t.x, t.y, t.z);
+}
+__device__ __forceinline__ void st3(float* __restrict__ p, uint32_t i, v3 v) {
+    packed3 t; t.x = v.x; t.y = v.y; t.z = v.z;
+    reinterpret_cast<packed3*>(p)[i] = t;
+}
+
 // integrate.hip
 void launch_step_full(phys_world* w, float dt, bool gravity);
 void launch_step_velocity_aabb(phys_world* w, float dt, bool gravity);

@@ -16,15 +16,12 @@ namespace phys {
 
 constexpr uint32_t kUncolored = 0xFFFFFFFFu;
 
-__device__ __forceinline__ v3 ld3g(const float* __restrict__ p, uint32_t i) {
-    return v3_make(p[3 * i], p[3 * i + 1], p[3 * i + 2]);
-}
 
 __device__ __forceinline__ geom_t load_geom(uint32_t i, const float* __restrict__ pos, const float* __restrict__ rot,
                                             const float* __restrict__ half_extent, const uint32_t* __restrict__ shape) {
     const float4 qq = reinterpret_cast<const float4*>(rot)[i];
     quat q; q.i = qq.x; q.j = qq.y; q.k = qq.z; q.w = qq.w;
-    return geom_make(ld3g(pos, i), q, ld3g(half_extent, i), shape[i]);
+    return geom_make(ld3(pos, i), q, ld3(half_extent, i), shape[i]);
 }
 
 constexpr int kNpThreads = 256;
@@ -36,7 +33,7 @@ __global__ __launch_bounds__(kNpThreads) void k_narrowphase(
     uint64_t max_manifolds, uint32_t* __restrict__ man_a, uint32_t* __restrict__ man_b,
     uint32_t* __restrict__ man_count, uint32_t* __restrict__ man_color, float* __restrict__ man_normal,
     float* __restrict__ man_points, uint64_t* __restrict__ man_prio, StepCounters* __restrict__ ctr) {
-    __shared__ uint32_t wcount[kNpThreads / 64];
+    __shared__ uint32_t wcount[kNpThreads / 64], wpts[kNpThreads / 64], wground[kNpThreads / 64];
     __shared__ uint32_t block_base;
     const uint32_t np_raw = ctr->n_pairs;
     const uint32_t n_pairs = (uint64_t)np_raw < max_pairs ? np_raw : (uint32_t)max_pairs;
@@ -62,15 +59,21 @@ __global__ __launch_bounds__(kNpThreads) void k_narrowphase(
         }
         const bool has = m.count > 0;
         const unsigned long long mask = __ballot(has);
-        if (lane == 0) wcount[wave] = (uint32_t)__popcll(mask);
+        const unsigned long long gmask = __ballot(has && b == PHYS_GROUND_ID);
         // contact points of this wave (for the stats counter)
         uint32_t pts = has ? (uint32_t)m.count : 0u;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) pts += (uint32_t)__shfl_xor((int)pts, off, 64);
+        if (lane == 0) {
+            wcount[wave] = (uint32_t)__popcll(mask);
+            wpts[wave] = pts;
+            wground[wave] = (uint32_t)__popcll(gmask);
+        }
         __syncthreads();
         if (threadIdx.x == 0) {
-            uint32_t t = 0;
-            for (int k = 0; k < kNpThreads / 64; ++k) t += wcount[k];
+            // one set of global atomics per workgroup: same-address atomics serialise chip-wide
+            uint32_t t = 0, tp = 0, tg = 0;
+            for (int k = 0; k < kNpThreads / 64; ++k) { t += wcount[k]; tp += wpts[k]; tg += wground[k]; }
             uint32_t bb = 0;
             if (t) {
                 bb = atomicAdd(&ctr->n_manifolds, t);
@@ -78,12 +81,11 @@ __global__ __launch_bounds__(kNpThreads) void k_narrowphase(
                 const uint32_t stored = (uint64_t)t <= room ? t : (uint32_t)room;
                 if (stored) atomicAdd(&ctr->n_uncolored, stored);
                 if (stored != t) atomicOr(&ctr->overflow, 2u);
+                atomicAdd(&ctr->n_contacts, tp);
+                if (tg) atomicAdd(&ctr->n_ground_manifolds, tg);
             }
             block_base = bb;
         }
-        if (lane == 0 && pts) atomicAdd(&ctr->n_contacts, pts);
-        const unsigned long long gmask = __ballot(has && b == PHYS_GROUND_ID);
-        if (lane == 0 && gmask) atomicAdd(&ctr->n_ground_manifolds, (uint32_t)__popcll(gmask));
         __syncthreads();
         if (has) {
             uint32_t woff = 0;
@@ -95,9 +97,7 @@ __global__ __launch_bounds__(kNpThreads) void k_narrowphase(
                 man_count[slot] = (uint32_t)m.count;
                 man_color[slot] = kUncolored;
                 man_prio[slot] = color_priority(a, b);
-                man_normal[3 * slot + 0] = m.normal.x;
-                man_normal[3 * slot + 1] = m.normal.y;
-                man_normal[3 * slot + 2] = m.normal.z;
+                st3(man_normal, (uint32_t)slot, m.normal);
                 float4* o = reinterpret_cast<float4*>(man_points) + 4 * slot;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) o[k] = make_float4(m.pt[k].x, m.pt[k].y, m.pt[k].z, m.depth[k]);
@@ -113,7 +113,7 @@ __device__ __forceinline__ uint32_t stored_manifolds(const StepCounters* ctr, ui
     return (uint64_t)m < max_manifolds ? m : (uint32_t)max_manifolds;
 }
 
-__global__ __launch_bounds__(256) void k_color_top(uint64_t max_manifolds, const uint32_t* __restrict__ man_a,
+__global__ __launch_bounds__(1024) void k_color_top(uint64_t max_manifolds, const uint32_t* __restrict__ man_a,
                                                    const uint32_t* __restrict__ man_b,
                                                    const uint32_t* __restrict__ man_color,
                                                    const uint64_t* __restrict__ man_prio,
@@ -131,66 +131,146 @@ __global__ __launch_bounds__(256) void k_color_top(uint64_t max_manifolds, const
     }
 }
 
-__global__ __launch_bounds__(256) void k_color_assign(uint64_t max_manifolds, const uint32_t* __restrict__ man_a,
-                                                      const uint32_t* __restrict__ man_b,
-                                                      uint32_t* __restrict__ man_color, uint32_t* __restrict__ man_slot,
-                                                      const uint64_t* __restrict__ man_prio,
-                                                      const unsigned long long* __restrict__ top,
-                                                      unsigned long long* __restrict__ top_next,
-                                                      unsigned long long* __restrict__ used,
-                                                      StepCounters* __restrict__ ctr) {
-    if (ctr->n_uncolored == 0) return;  // uniform: n_uncolored only changes through the atomics below,
-                                        // and a stale non-zero read only costs an idle pass
+constexpr int kColorThreads = 1024;
+
+__global__ __launch_bounds__(kColorThreads) void k_color_assign(uint64_t max_manifolds, const uint32_t* __restrict__ man_a,
+                                                               const uint32_t* __restrict__ man_b,
+                                                               uint32_t* __restrict__ man_color,
+                                                               const uint64_t* __restrict__ man_prio,
+                                                               const unsigned long long* __restrict__ top,
+                                                               unsigned long long* __restrict__ top_next,
+                                                               unsigned long long* __restrict__ used,
+                                                               StepCounters* __restrict__ ctr) {
+    // block-uniform early exit (other workgroups decrement n_uncolored while this one starts, so every
+    // thread must act on the SAME read: a barrier follows)
+    __shared__ uint32_t s_uncolored;
+    __shared__ uint32_t s_wins[kColorThreads / 64];
+    if (threadIdx.x == 0) s_uncolored = ctr->n_uncolored;
+    __syncthreads();
+    if (s_uncolored == 0) return;
     const uint32_t M = stored_manifolds(ctr, max_manifolds);
-    const int lane = threadIdx.x & 63;
-    const uint32_t stride = gridDim.x * blockDim.x;
-    const uint32_t trips = (M + stride - 1) / stride;
-    uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
-    for (uint32_t trip = 0; trip < trips; ++trip, m += stride) {
-        bool winner = false;
-        uint32_t c = 0;
-        if (m < M && man_color[m] == kUncolored) {
-            const unsigned long long p = man_prio[m];
-            const uint32_t a = man_a[m], b = man_b[m];
-            const bool gb = b == PHYS_GROUND_ID;
-            if (top[a] == p && (gb || top[b] == p)) {
-                winner = true;
-                unsigned long long mask = used[a];
-                if (!gb) mask |= used[b];
-                while (c < (uint32_t)(PHYS_MAX_COLORS - 1) && ((mask >> c) & 1ull)) ++c;
-                if (((mask >> c) & 1ull)) atomicOr(&ctr->overflow, 4u);  // more than PHYS_MAX_COLORS at one body
-                // the winner is the only manifold touching a or b that colours this round
-                used[a] = used[a] | (1ull << c);
-                if (!gb) used[b] = used[b] | (1ull << c);
-                man_color[m] = c;
-            } else {
-                top_next[a] = 0ull;  // losers clear the other buffer for the next round
-                if (!gb) top_next[b] = 0ull;
+    uint32_t wins = 0;
+    for (uint32_t m = blockIdx.x * blockDim.x + threadIdx.x; m < M; m += gridDim.x * blockDim.x) {
+        if (man_color[m] != kUncolored) continue;
+        const unsigned long long p = man_prio[m];
+        const uint32_t a = man_a[m], b = man_b[m];
+        const bool gb = b == PHYS_GROUND_ID;
+        if (top[a] == p && (gb || top[b] == p)) {
+            unsigned long long mask = used[a];
+            if (!gb) mask |= used[b];
+            uint32_t c = 0;
+            while (c < (uint32_t)(PHYS_MAX_COLORS - 1) && ((mask >> c) & 1ull)) ++c;
+            if (((mask >> c) & 1ull)) atomicOr(&ctr->overflow, 4u);  // more than PHYS_MAX_COLORS at one body
+            // the winner is the only manifold touching a or b that colours this round
+            used[a] = used[a] | (1ull << c);
+            if (!gb) used[b] = used[b] | (1ull << c);
+            man_color[m] = c;
+            ++wins;
+        } else {
+            top_next[a] = 0ull;  // losers clear the other buffer for the next round
+            if (!gb) top_next[b] = 0ull;
+        }
+    }
+    // ONE global atomic per workgroup (same-address atomics serialise chip-wide at ~88 per microsecond)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) wins += (uint32_t)__shfl_xor((int)wins, off, 64);
+    if ((threadIdx.x & 63) == 0) s_wins[threadIdx.x >> 6] = wins;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t t = 0;
+        for (int k = 0; k < kColorThreads / 64; ++k) t += s_wins[k];
+        if (t) atomicSub(&ctr->n_uncolored, t);
+    }
+}
+
+// ---- colour-major renumbering: counting sort of the manifolds by colour ---------------------------
+// hist (per-workgroup colour histogram) -> offsets (one workgroup scans colour-major) -> place.
+// No global atomics; the order inside a colour is (workgroup, arrival), which nothing depends on.
+constexpr int kSortBlocks = 512;   // workgroups of the hist / place kernels (fixed, so the scan is small)
+constexpr int kSortChunk = 4096;   // manifolds per workgroup trip
+
+__global__ __launch_bounds__(1024) void k_color_hist(uint64_t max_manifolds, const uint32_t* __restrict__ man_color,
+                                                     uint32_t* __restrict__ block_hist /*[colour][kSortBlocks]*/,
+                                                     const StepCounters* __restrict__ ctr) {
+    __shared__ uint32_t h[PHYS_MAX_COLORS];
+    if (threadIdx.x < PHYS_MAX_COLORS) h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t M = stored_manifolds(ctr, max_manifolds);
+    for (uint32_t base = blockIdx.x * kSortChunk; base < M; base += gridDim.x * kSortChunk) {
+#pragma unroll
+        for (int k = 0; k < kSortChunk / 1024; ++k) {
+            const uint32_t m = base + k * 1024 + threadIdx.x;
+            if (m < M) {
+                const uint32_t c = man_color[m];
+                if (c < (uint32_t)PHYS_MAX_COLORS) atomicAdd(&h[c], 1u);
             }
         }
-        // slot of each winner inside its colour: one atomic per (wave, colour)
-        unsigned long long pending = __ballot(winner);
-        if (pending) {
-            const uint32_t wins = (uint32_t)__popcll(pending);
-            uint32_t cmax = winner ? c + 1 : 0;
+    }
+    __syncthreads();
+    if (threadIdx.x < PHYS_MAX_COLORS) block_hist[threadIdx.x * kSortBlocks + blockIdx.x] = h[threadIdx.x];
+}
+
+// one workgroup: exclusive scan of block_hist in colour-major order (in place) + per-colour totals
+__global__ __launch_bounds__(1024) void k_color_offsets(uint32_t* __restrict__ block_hist, StepCounters* __restrict__ ctr) {
+    __shared__ uint32_t wtot[16];
+    __shared__ uint32_t carry_s;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    constexpr uint32_t kPerColor = kSortBlocks;
+    constexpr uint32_t kTotal = PHYS_MAX_COLORS * kPerColor;
+    uint32_t ncol = 0;
+    for (uint32_t base = 0; base < kTotal; base += 1024) {
+        const uint32_t idx = base + threadIdx.x;
+        const uint32_t v = block_hist[idx];
+        uint32_t inc = v;
+        const int lane = threadIdx.x & 63;
 #pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                const uint32_t o = (uint32_t)__shfl_xor((int)cmax, off, 64);
-                cmax = o > cmax ? o : cmax;
-            }
-            if (lane == 0) {
-                atomicSub(&ctr->n_uncolored, wins);
-                atomicMax(&ctr->n_colors, cmax);
-            }
-            while (pending) {
-                const int leader = __ffsll((long long)pending) - 1;
-                const uint32_t c0 = (uint32_t)__shfl((int)c, leader, 64);
-                const unsigned long long same = __ballot(winner && c == c0);
-                uint32_t base = 0;
-                if (lane == leader) base = atomicAdd(&ctr->color_count[c0], (uint32_t)__popcll(same));
-                base = (uint32_t)__shfl((int)base, leader, 64);
-                if (winner && c == c0) man_slot[m] = base + (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
-                pending &= ~same;
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t o = (uint32_t)__shfl_up((int)inc, off, 64);
+            if (lane >= off) inc += o;
+        }
+        if (lane == 63) wtot[threadIdx.x >> 6] = inc;
+        __syncthreads();
+        uint32_t woff = 0;
+        for (uint32_t k = 0; k < (threadIdx.x >> 6); ++k) woff += wtot[k];
+        const uint32_t carry = carry_s;
+        const uint32_t excl = carry + woff + inc - v;
+        block_hist[idx] = excl;
+        if (idx % kPerColor == 0) ctr->color_start[idx / kPerColor] = excl;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = carry + woff + inc;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) ctr->color_start[PHYS_MAX_COLORS] = carry_s;
+    __syncthreads();
+    if (threadIdx.x < PHYS_MAX_COLORS) {
+        const uint32_t cnt = ctr->color_start[threadIdx.x + 1] - ctr->color_start[threadIdx.x];
+        ctr->color_count[threadIdx.x] = cnt;
+        uint32_t cmax = cnt ? threadIdx.x + 1 : 0;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const uint32_t o = (uint32_t)__shfl_xor((int)cmax, off, 64);
+            cmax = o > cmax ? o : cmax;
+        }
+        ncol = cmax;
+        if (threadIdx.x == 0) ctr->n_colors = ncol;
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_color_place(uint64_t max_manifolds, const uint32_t* __restrict__ man_color,
+                                                      const uint32_t* __restrict__ block_off /*scanned block_hist*/,
+                                                      uint32_t* __restrict__ row_src, const StepCounters* __restrict__ ctr) {
+    __shared__ uint32_t cursor[PHYS_MAX_COLORS];
+    if (threadIdx.x < PHYS_MAX_COLORS) cursor[threadIdx.x] = block_off[threadIdx.x * kSortBlocks + blockIdx.x];
+    __syncthreads();
+    const uint32_t M = stored_manifolds(ctr, max_manifolds);
+    for (uint32_t base = blockIdx.x * kSortChunk; base < M; base += gridDim.x * kSortChunk) {
+#pragma unroll
+        for (int k = 0; k < kSortChunk / 1024; ++k) {
+            const uint32_t m = base + k * 1024 + threadIdx.x;
+            if (m < M) {
+                const uint32_t c = man_color[m];
+                if (c < (uint32_t)PHYS_MAX_COLORS) row_src[atomicAdd(&cursor[c], 1u)] = m;
             }
         }
     }
@@ -212,27 +292,31 @@ void launch_narrowphase(phys_world* w) {
 static void launch_color_round(phys_world* w, uint32_t round, unsigned blocks) {
     unsigned long long* top = w->body_top.p + (round & 1u) * w->n;
     unsigned long long* top_next = w->body_top.p + ((round + 1u) & 1u) * w->n;
-    { PHYS_PROF(w, PHYS_STAGE_COLOR); hipLaunchKernelGGL(k_color_top, dim3(blocks), dim3(256), 0, w->stream, w->max_manifolds, w->man_a.p, w->man_b.p,
+    { PHYS_PROF(w, PHYS_STAGE_COLOR); hipLaunchKernelGGL(k_color_top, dim3(blocks), dim3(kColorThreads), 0, w->stream, w->max_manifolds, w->man_a.p, w->man_b.p,
                        w->man_color.p, w->man_prio.p, top, w->counters.p); }
-    { PHYS_PROF(w, PHYS_STAGE_COLOR); hipLaunchKernelGGL(k_color_assign, dim3(blocks), dim3(256), 0, w->stream, w->max_manifolds, w->man_a.p, w->man_b.p,
-                       w->man_color.p, w->man_slot.p, w->man_prio.p, top, top_next, w->body_used.p, w->counters.p); }
+    { PHYS_PROF(w, PHYS_STAGE_COLOR); hipLaunchKernelGGL(k_color_assign, dim3(blocks), dim3(kColorThreads), 0, w->stream, w->max_manifolds, w->man_a.p, w->man_b.p,
+                       w->man_color.p, w->man_prio.p, top, top_next, w->body_used.p, w->counters.p); }
 }
 
-// Runs colouring rounds until the device reports no uncoloured manifold, then leaves the final counters
-// in w->h_counters (the solver launch sizes come from them). One host check per step in the steady state.
+// Runs colouring rounds until the device reports no uncoloured manifold, then the counting sort by colour;
+// leaves the final counters (manifold count, colour ranges) in w->h_counters for the solver launch sizes.
+// Steady state: ONE host check per step (the round count of the previous step + 1 is launched up front,
+// together with the speculative histogram + offsets).
 void launch_coloring(phys_world* w) {
     const uint64_t n = w->n;
     if (n == 0) return;
     hipStream_t s = w->stream;
     { PHYS_PROF(w, PHYS_STAGE_COLOR); (void)hipMemsetAsync(w->body_used.p, 0, n * 8, s); }
     { PHYS_PROF(w, PHYS_STAGE_COLOR); (void)hipMemsetAsync(w->body_top.p, 0, 2 * n * 8, s); }
-    uint64_t blocks64 = (w->max_manifolds + 255) / 256;
-    if (blocks64 > 256 * 8) blocks64 = 256 * 8;
+    uint64_t blocks64 = (w->max_manifolds + kColorThreads - 1) / kColorThreads;
+    if (blocks64 > 512) blocks64 = 512;
     const unsigned blocks = (unsigned)blocks64;
     uint32_t round = 0;
     uint32_t batch = w->color_rounds_hint;
     for (int guard = 0; guard < 64; ++guard) {
         for (uint32_t k = 0; k < batch; ++k) launch_color_round(w, round++, blocks);
+        { PHYS_PROF(w, PHYS_STAGE_ROWS); hipLaunchKernelGGL(k_color_hist, dim3(kSortBlocks), dim3(1024), 0, s, w->max_manifolds, w->man_color.p, w->color_block_hist.p, w->counters.p); }
+        { PHYS_PROF(w, PHYS_STAGE_ROWS); hipLaunchKernelGGL(k_color_offsets, dim3(1), dim3(1024), 0, s, w->color_block_hist.p, w->counters.p); }
         (void)hipMemcpyAsync(w->h_counters, w->counters.p, sizeof(StepCounters), hipMemcpyDeviceToHost, s);
         (void)hipStreamSynchronize(s);
         if (w->prof.on) w->prof.collect(s);
@@ -241,6 +325,10 @@ void launch_coloring(phys_world* w) {
     }
     const uint32_t used_rounds = w->h_counters->color_rounds;
     w->color_rounds_hint = used_rounds + 1 > 2 ? used_rounds + 1 : 2;
+    if (w->h_counters->n_manifolds && !w->h_counters->overflow) {
+        PHYS_PROF(w, PHYS_STAGE_ROWS);
+        hipLaunchKernelGGL(k_color_place, dim3(kSortBlocks), dim3(1024), 0, s, w->max_manifolds, w->man_color.p, w->color_block_hist.p, w->row_src.p, w->counters.p);
+    }
 }
 
 }  // namespace phys

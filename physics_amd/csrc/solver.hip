@@ -23,25 +23,11 @@ struct ColorTable {
 constexpr int kRowPlanesPerPoint = 10;  // rA xyz, rB xyz, normal mass, tangent mass 0/1, bias
 constexpr int kAccPlanesPerPoint = 3;   // pn, pt0, pt1
 
-__device__ __forceinline__ v3 ld3s(const float* __restrict__ p, uint32_t i) {
-    return v3_make(p[3 * i], p[3 * i + 1], p[3 * i + 2]);
-}
-__device__ __forceinline__ void st3s(float* __restrict__ p, uint32_t i, v3 v) {
-    p[3 * i] = v.x; p[3 * i + 1] = v.y; p[3 * i + 2] = v.z;
-}
 __device__ __forceinline__ m33 ld_m33(const float* __restrict__ p, uint32_t i) {
     m33 M;
 #pragma unroll
     for (int k = 0; k < 9; ++k) M.m[k] = p[9 * (size_t)i + k];
     return M;
-}
-
-// row index of every manifold: colour-major
-__global__ __launch_bounds__(256) void k_row_src(uint32_t M, ColorTable ct, const uint32_t* __restrict__ man_color,
-                                                 const uint32_t* __restrict__ man_slot, uint32_t* __restrict__ row_src) {
-    const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
-    if (m >= M) return;
-    row_src[ct.start[man_color[m]] + man_slot[m]] = m;
 }
 
 __global__ __launch_bounds__(256) void k_rows_build(uint32_t M, uint64_t cap, solve_params_t sp,
@@ -61,7 +47,7 @@ __global__ __launch_bounds__(256) void k_rows_build(uint32_t M, uint64_t cap, so
     manifold_t g;
     const uint32_t a = man_a[m], b = man_b[m];
     g.count = (int)man_count[m];
-    g.normal = ld3s(man_normal, m);
+    g.normal = ld3(man_normal, m);
     const float4* pp = reinterpret_cast<const float4*>(man_points) + 4 * (size_t)m;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -76,9 +62,9 @@ __global__ __launch_bounds__(256) void k_rows_build(uint32_t M, uint64_t cap, so
     for (int k = 0; k < 9; ++k) IB.m[k] = 0.0f;
     float imb = 0.0f;
     v3 xB = v3_make(0.0f, 0.0f, 0.0f);
-    if (has_b) { IB = ld_m33(inv_inertia, b); imb = inv_mass[b]; xB = ld3s(pos, b); }
+    if (has_b) { IB = ld_m33(inv_inertia, b); imb = inv_mass[b]; xB = ld3(pos, b); }
     solver_manifold_t sm;
-    solver_prep(&g, has_b, ld3s(pos, a), xB, inv_mass[a], &IA, imb, &IB, &sp, &sm);
+    solver_prep(&g, has_b, ld3(pos, a), xB, inv_mass[a], &IA, imb, &IB, &sp, &sm);
     row_a[d] = a; row_b[d] = b; row_count[d] = (uint32_t)sm.count;
     row_normal[0 * cap + d] = sm.n.x; row_normal[1 * cap + d] = sm.n.y; row_normal[2 * cap + d] = sm.n.z;
 #pragma unroll
@@ -133,16 +119,16 @@ __global__ __launch_bounds__(256) void k_solve_color(uint32_t start, uint32_t co
     }
     const m33 IA = ld_m33(inv_inertia, a);
     const float ima = inv_mass[a];
-    v3 vA = ld3s(lin, a), wA = ld3s(ang, a);
+    v3 vA = ld3(lin, a), wA = ld3(ang, a);
     m33 IB;
 #pragma unroll
     for (int k = 0; k < 9; ++k) IB.m[k] = 0.0f;
     float imb = 0.0f;
     v3 vB = v3_make(0.0f, 0.0f, 0.0f), wB = v3_make(0.0f, 0.0f, 0.0f);
-    if (sm.has_b) { IB = ld_m33(inv_inertia, b); imb = inv_mass[b]; vB = ld3s(lin, b); wB = ld3s(ang, b); }
+    if (sm.has_b) { IB = ld_m33(inv_inertia, b); imb = inv_mass[b]; vB = ld3(lin, b); wB = ld3(ang, b); }
     solve_manifold(&sm, friction, ima, &IA, imb, &IB, &vA, &wA, &vB, &wB);
-    st3s(lin, a, vA); st3s(ang, a, wA);
-    if (sm.has_b) { st3s(lin, b, vB); st3s(ang, b, wB); }
+    st3(lin, a, vA); st3(ang, a, wA);
+    if (sm.has_b) { st3(lin, b, vB); st3(ang, b, wB); }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         if (k < sm.count) {
@@ -160,11 +146,7 @@ void launch_solver(phys_world* w, float dt) {
     if (M == 0 || w->n == 0) return;
     const uint32_t ncol = c.n_colors;
     ColorTable ct;
-    uint32_t run = 0;
-    for (uint32_t k = 0; k <= (uint32_t)kMaxColors; ++k) {
-        ct.start[k] = run;
-        if (k < (uint32_t)kMaxColors) run += (k < ncol) ? c.color_count[k] : 0u;
-    }
+    for (uint32_t k = 0; k <= (uint32_t)kMaxColors; ++k) ct.start[k] = c.color_start[k];  // from k_color_offsets
     solve_params_t sp;
     sp.dt = dt;
     sp.baumgarte = w->cfg.baumgarte;
@@ -174,7 +156,6 @@ void launch_solver(phys_world* w, float dt) {
     hipStream_t s = w->stream;
     const uint64_t cap = w->max_manifolds;
     const dim3 gm((M + 255) / 256), tb(256);
-    { PHYS_PROF(w, PHYS_STAGE_ROWS); hipLaunchKernelGGL(k_row_src, gm, tb, 0, s, M, ct, w->man_color.p, w->man_slot.p, w->row_src.p); }
     { PHYS_PROF(w, PHYS_STAGE_ROWS); hipLaunchKernelGGL(k_rows_build, gm, tb, 0, s, M, cap, sp, w->row_src.p, w->man_a.p, w->man_b.p, w->man_count.p,
                        w->man_normal.p, w->man_points.p, w->pos.p, w->inv_mass.p, w->inv_inertia.p, w->row_a.p,
                        w->row_b.p, w->row_count.p, w->row_normal.p, w->row_data.p, w->row_acc.p); }

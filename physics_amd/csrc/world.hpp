@@ -156,6 +156,7 @@ struct phys_world {
     phys::DevBuf<float> man_normal;      // 3 per manifold
     phys::DevBuf<float> man_points;      // 16 per manifold: 4 x (xyz, depth)
     phys::DevBuf<uint64_t> man_prio;
+    phys::DevBuf<uint32_t> color_block_hist;  // [colour][workgroup] histogram / offsets of the colour sort
     // colouring state
     phys::DevBuf<unsigned long long> body_top, body_used;
     // solver rows, colour-sorted SoA
