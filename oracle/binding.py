@@ -50,6 +50,8 @@ def load():
         "oracle_get_lambda": (C.c_int32, [vp, f32p, C.c_uint64, u64p]),
         "oracle_get_stats": (C.c_int32, [vp, C.POINTER(PhysStats)]),
         "oracle_broadphase": (C.c_int32, [vp, u32p, C.c_uint64, u64p]),
+        "oracle_broadphase_grid": (C.c_int32, [vp, u32p, C.c_uint64, u64p]),
+        "oracle_collide_now": (C.c_int32, [vp]),
         "oracle_get_aabbs": (C.c_int32, [vp, f32p]),
         "oracle_get_manifolds": (C.c_int32, [vp, u32p, u32p, f32p, f32p, C.c_uint64, u64p]),
         "oracle_get_colors": (C.c_int32, [vp, u32p, C.c_uint64]),
@@ -203,6 +205,17 @@ class OracleWorld:
             self._ck(self.lib.oracle_broadphase(self.h, _p(out, u32p), n.value, C.byref(n)))
         return out
 
+    def broadphase_grid(self):
+        n = C.c_uint64()
+        self._ck(self.lib.oracle_broadphase_grid(self.h, None, 0, C.byref(n)))
+        out = np.empty((n.value, 2), np.uint32)
+        if n.value:
+            self._ck(self.lib.oracle_broadphase_grid(self.h, _p(out, u32p), n.value, C.byref(n)))
+        return out
+
+    def collide_now(self):
+        self._ck(self.lib.oracle_collide_now(self.h))
+
     def get_aabbs(self):
         out = np.empty((self.n, 6), np.float32)
         self._ck(self.lib.oracle_get_aabbs(self.h, _p(out)))
@@ -282,4 +295,36 @@ def det_atan2(y, x):
     y, x = _f(y), _f(x)
     out = np.empty_like(x)
     load().oracle_det_atan2(_p(y), _p(x), x.size, _p(out))
+    return out
+
+
+def libm_sincos(x):
+    """glibc sinf / cosf through the oracle library (numpy's float32 sin is NOT glibc's)."""
+    lib = load()
+    lib.oracle_libm_sincos.restype = None
+    lib.oracle_libm_sincos.argtypes = [f32p, C.c_uint64, f32p, f32p]
+    x = _f(x)
+    s = np.empty_like(x)
+    c = np.empty_like(x)
+    lib.oracle_libm_sincos(_p(x), x.size, _p(s), _p(c))
+    return s, c
+
+
+def libm_asin(x):
+    lib = load()
+    lib.oracle_libm_asin.restype = None
+    lib.oracle_libm_asin.argtypes = [f32p, C.c_uint64, f32p]
+    x = _f(x)
+    out = np.empty_like(x)
+    lib.oracle_libm_asin(_p(x), x.size, _p(out))
+    return out
+
+
+def libm_atan2(y, x):
+    lib = load()
+    lib.oracle_libm_atan2.restype = None
+    lib.oracle_libm_atan2.argtypes = [f32p, f32p, C.c_uint64, f32p]
+    y, x = _f(y), _f(x)
+    out = np.empty_like(x)
+    lib.oracle_libm_atan2(_p(y), _p(x), x.size, _p(out))
     return out

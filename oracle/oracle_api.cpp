@@ -2,6 +2,7 @@
 // code. Loaded only by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg
 // (through oracle/binding.py). Mirrors the argument conventions of include/physics_hip.h so the
 // same seeded inputs can be fed to both.
+#include <cmath>
 #include <cstring>
 #include <string>
 
@@ -215,6 +216,26 @@ int32_t oracle_broadphase(oracle_world* w, uint32_t* pairs_out, uint64_t cap, ui
         }
     return PHYS_OK;
 }
+// broad phase by the uniform-grid driver (the timed baseline path); oracle_broadphase uses sort-and-sweep
+int32_t oracle_broadphase_grid(oracle_world* w, uint32_t* pairs_out, uint64_t cap, uint64_t* n_pairs) {
+    w->col.compute_aabbs(w->state.entities);
+    w->col.broadphase_grid();
+    *n_pairs = w->col.pairs.size();
+    if (pairs_out)
+        for (size_t k = 0; k < w->col.pairs.size() && k < cap; ++k) {
+            pairs_out[2 * k] = w->col.pairs[k].first;
+            pairs_out[2 * k + 1] = w->col.pairs[k].second;
+        }
+    return PHYS_OK;
+}
+// AABBs + broad phase + narrow phase + colouring of the CURRENT poses, without stepping (for the KATs)
+int32_t oracle_collide_now(oracle_world* w) {
+    w->col.compute_aabbs(w->state.entities);
+    w->col.broadphase_sweep();
+    w->col.narrowphase(w->state.entities);
+    w->col.color_manifolds(w->state.entities.size());
+    return PHYS_OK;
+}
 int32_t oracle_get_aabbs(oracle_world* w, float* out) {
     w->col.compute_aabbs(w->state.entities);
     std::memcpy(out, w->col.aabb.data(), w->col.aabb.size() * sizeof(float));
@@ -281,6 +302,16 @@ void oracle_quat_euler_angles(const float* q, int32_t trig, float* out) {
 // det_math probes (tests/test_det_math.py compares them with glibc)
 void oracle_det_sincos(const float* x, uint64_t n, float* s, float* c) {
     for (uint64_t k = 0; k < n; ++k) { s[k] = det_sinf(x[k]); c[k] = det_cosf(x[k]); }
+}
+// the host libm's own float routines (glibc sinf/cosf/asinf/atan2f: what Rust's f32::sin etc. call)
+void oracle_libm_sincos(const float* x, uint64_t n, float* s, float* c) {
+    for (uint64_t k = 0; k < n; ++k) { s[k] = sinf(x[k]); c[k] = cosf(x[k]); }
+}
+void oracle_libm_asin(const float* x, uint64_t n, float* out) {
+    for (uint64_t k = 0; k < n; ++k) out[k] = asinf(x[k]);
+}
+void oracle_libm_atan2(const float* y, const float* x, uint64_t n, float* out) {
+    for (uint64_t k = 0; k < n; ++k) out[k] = atan2f(y[k], x[k]);
 }
 void oracle_det_asin(const float* x, uint64_t n, float* out) {
     for (uint64_t k = 0; k < n; ++k) out[k] = det_asinf(x[k]);

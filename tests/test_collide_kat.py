@@ -1,0 +1,189 @@
+"""CPU: analytic known-answer tests for the collision-stage specification (include/spec/collide.h,
+contact_solve.h) evaluated through the oracle. These stages have no reference counterpart (SURVEY §8
+A10-A12: "parity unpinned" by the reference), so closed-form answers are what pins them."""
+import numpy as np
+import pytest
+
+from oracle import binding as ob
+from physics_amd import (FLAG_COLLISIONS, FLAG_GROUND_PLANE, GROUND_ID, SHAPE_BOX, SHAPE_NONE, SHAPE_SPHERE,
+                         default_config, scenes)
+
+DT = scenes.DT_NANOS
+MARGIN = 0.02
+
+
+def world(flags=FLAG_COLLISIONS, **kw):
+    return ob.OracleWorld(default_config(flags=flags, gravity_offset=(0, 0, 0), **kw), trig=ob.TRIG_DET)
+
+
+def boxes(n, he=1.0):
+    return np.full(n, SHAPE_BOX, np.uint32), np.full((n, 3), he, np.float32)
+
+
+# ---- A10 broad phase ------------------------------------------------------------------------------
+@pytest.mark.parametrize("dx,expect", [(1.5, 1), (2.0, 1), (2.0 + 2 * MARGIN, 1), (2.0 + 2 * MARGIN + 1e-3, 0), (3.0, 0)])
+def test_two_unit_aabbs_overlap_touch_disjoint(dx, expect):
+    w = world()
+    st, he = boxes(2)
+    w.set_bodies(np.array([[0, 0, 0], [dx, 0, 0]], np.float32), shape_type=st, half_extent=he)
+    assert len(w.broadphase()) == expect
+    assert len(w.broadphase_grid()) == expect
+
+
+def test_aabb_of_rotated_box_and_sphere():
+    w = world()
+    q45 = np.array([0, 0, np.sin(np.pi / 8), np.cos(np.pi / 8)], np.float32)  # 45 deg about z
+    w.set_bodies(np.array([[0, 0, 0], [10, 5, 0], [20, 0, 0]], np.float32),
+                 rot=np.stack([q45, [0, 0, 0, 1], [0, 0, 0, 1]]).astype(np.float32),
+                 shape_type=np.array([SHAPE_BOX, SHAPE_SPHERE, SHAPE_NONE], np.uint32),
+                 half_extent=np.array([[1, 1, 1], [0.5, 9, 9], [1, 1, 1]], np.float32))
+    a = w.get_aabbs()
+    r = np.sqrt(2.0) + MARGIN
+    assert np.allclose(a[0], [-r, -r, -1 - MARGIN, r, r, 1 + MARGIN], atol=1e-6)
+    assert np.allclose(a[1], [9.5 - MARGIN, 4.5 - MARGIN, -0.5 - MARGIN, 10.5 + MARGIN, 5.5 + MARGIN, 0.5 + MARGIN], atol=1e-6)
+    assert (a[2, :3] > a[2, 3:]).all()  # NONE: inverted box, never overlaps
+
+
+def test_lattice_has_exactly_the_face_neighbour_pairs():
+    nx, ny, nz = 6, 5, 4
+    pos = scenes.lattice(nx, ny, nz, 1.9, 5.0, 0.0)  # spacing < 2: faces overlap, diagonals do too
+    st, he = boxes(len(pos))
+    w = world()
+    w.set_bodies(pos, shape_type=st, half_extent=he)
+    full = (3 * nx - 2) * (3 * ny - 2) * (3 * nz - 2)  # ordered 26-neighbour incidences + self
+    expect_26 = (full - nx * ny * nz) // 2
+    assert len(w.broadphase()) == expect_26
+    pos2 = scenes.lattice(nx, ny, nz, 2.03, 5.0, 0.0)  # gap 0.03 < 2*margin: only nothing but faces... none diag
+    w.set_bodies(pos2, shape_type=st, half_extent=he)
+    # every axis gap is 0.03 <= 2*margin, so faces, edges and corners all still overlap
+    assert len(w.broadphase()) == expect_26
+    pos3 = scenes.lattice(nx, ny, nz, 2.5, 5.0, 0.0)
+    w.set_bodies(pos3, shape_type=st, half_extent=he)
+    assert len(w.broadphase()) == 0
+
+
+def test_sweep_and_grid_drivers_agree_on_a_random_soup():
+    rng = np.random.default_rng(5)
+    n = 3000
+    pos = rng.uniform(-15, 15, size=(n, 3)).astype(np.float32)
+    q = rng.normal(size=(n, 4)).astype(np.float32)
+    q /= np.linalg.norm(q, axis=1, keepdims=True).astype(np.float32)
+    st = rng.integers(0, 3, n).astype(np.uint32)
+    he = rng.uniform(0.2, 1.5, size=(n, 3)).astype(np.float32)
+    w = world()
+    w.set_bodies(pos, rot=q, shape_type=st, half_extent=he)
+    a, b = w.broadphase(), w.broadphase_grid()
+    assert len(a) > 1000 and np.array_equal(a, b)
+    # brute force on a subset
+    bb = w.get_aabbs()[:400]
+    brute = [(i, j) for i in range(400) for j in range(i + 1, 400)
+             if (bb[i, :3] <= bb[j, 3:]).all() and (bb[j, :3] <= bb[i, 3:]).all()]
+    sub = [tuple(p) for p in a if p[0] < 400 and p[1] < 400]
+    assert sub == brute
+
+
+# ---- A11 narrow phase -----------------------------------------------------------------------------
+def test_sphere_sphere_closed_form():
+    w = world()
+    d = np.array([1.2, 0.9, -0.4], np.float32)
+    w.set_bodies(np.stack([np.zeros(3, np.float32), d]), shape_type=np.full(2, SHAPE_SPHERE, np.uint32),
+                 half_extent=np.array([[1.0, 0, 0], [0.7, 0, 0]], np.float32))
+    w.collide_now()
+    ids, counts, normals, points = w.get_manifolds()
+    dist = np.linalg.norm(d.astype(np.float64))
+    assert ids.tolist() == [[0, 1]] and counts[0] == 1
+    assert np.allclose(normals[0], d / dist, atol=1e-6)
+    assert abs(points[0, 0, 3] - (1.7 - dist)) < 1e-6
+    assert np.allclose(points[0, 0, :3], (d / dist) * (1.0 - (1.7 - dist) / 2), atol=1e-6)
+
+
+def test_cube_resting_on_plane_gives_four_bottom_corners():
+    w = world(FLAG_COLLISIONS | FLAG_GROUND_PLANE)
+    st, he = boxes(1)
+    y = 0.99
+    w.set_bodies(np.array([[3, y, -2]], np.float32), shape_type=st, half_extent=he)
+    w.collide_now()
+    ids, counts, normals, points = w.get_manifolds()
+    assert ids.tolist() == [[0, GROUND_ID]] and counts[0] == 4
+    assert np.array_equal(normals[0], np.array([0, -1, 0], np.float32))  # A (body) -> B (ground)
+    corners = sorted(tuple(np.round(p[:3], 5)) for p in points[0])
+    assert corners == sorted([(2.0, y - 1, -3.0), (4.0, y - 1, -3.0), (2.0, y - 1, -1.0), (4.0, y - 1, -1.0)])
+    assert np.allclose(points[0, :, 3], 1.0 - y, atol=1e-6)  # depth = -(y - 1)
+
+
+def test_box_box_face_contact_and_sphere_box():
+    w = world()
+    st, he = boxes(2)
+    w.set_bodies(np.array([[0, 0, 0], [0.5, 1.9, 0.25]], np.float32), shape_type=st, half_extent=he)
+    w.collide_now()
+    ids, counts, normals, points = w.get_manifolds()
+    assert counts[0] == 4 and np.allclose(normals[0], [0, 1, 0])
+    assert np.allclose(points[0, :, 3], 0.1, atol=1e-6)
+    xs = sorted(set(np.round(points[0, :, 0], 5)))
+    zs = sorted(set(np.round(points[0, :, 2], 5)))
+    assert xs == [-0.5, 1.0] and zs == [-0.75, 1.0]  # overlap rectangle of the two faces
+    # sphere above a box face
+    w.set_bodies(np.array([[0, 0, 0], [0.3, 1.4, -0.2]], np.float32),
+                 shape_type=np.array([SHAPE_BOX, SHAPE_SPHERE], np.uint32),
+                 half_extent=np.array([[1, 1, 1], [0.5, 0, 0]], np.float32))
+    w.collide_now()
+    ids, counts, normals, points = w.get_manifolds()
+    assert counts[0] == 1 and np.allclose(normals[0], [0, 1, 0]) and abs(points[0, 0, 3] - 0.1) < 1e-6
+    assert np.allclose(points[0, 0, :3], [0.3, 1.0, -0.2], atol=1e-6)
+
+
+def test_box_box_edge_edge_contact():
+    w = world()
+    st, he = boxes(2)
+    qx = np.array([np.sin(np.pi / 8), 0, 0, np.cos(np.pi / 8)], np.float32)  # 45 deg about x
+    qz = np.array([0, 0, np.sin(np.pi / 8), np.cos(np.pi / 8)], np.float32)  # 45 deg about z
+    gap = 2 * np.sqrt(2.0) - 0.05
+    w.set_bodies(np.array([[0, 0, 0], [0, gap, 0]], np.float32), rot=np.stack([qz, qx]), shape_type=st, half_extent=he)
+    w.collide_now()
+    ids, counts, normals, points = w.get_manifolds()
+    assert counts[0] == 1 and np.allclose(np.abs(normals[0]), [0, 1, 0], atol=1e-5)
+    assert abs(points[0, 0, 3] - 0.05) < 1e-4
+
+
+# ---- A12 solver -----------------------------------------------------------------------------------
+def test_single_cube_comes_to_rest_on_the_plane():
+    w = world(FLAG_COLLISIONS | FLAG_GROUND_PLANE)
+    st, he = boxes(1)
+    w.set_bodies(np.array([[0, 3.0, 0]], np.float32), shape_type=st, half_extent=he)
+    w.update_n(DT, 400)
+    pos, rot = w.get_transforms()
+    lin, ang = w.get_velocities()
+    assert abs(pos[0, 1] - 1.0) < 0.02  # rest at y = 1 +- slop
+    assert np.abs(lin).max() < 0.2 and np.abs(ang).max() < 1e-3
+
+
+def test_symmetric_head_on_hit_conserves_linear_momentum():
+    w = world(gravity_force=(0, 0, 0), friction=0.0)
+    w.set_bodies(np.array([[-1.5, 0, 0], [1.5, 0, 0]], np.float32), lin_vel=np.array([[2, 0, 0], [-2, 0, 0]], np.float32),
+                 shape_type=np.full(2, SHAPE_SPHERE, np.uint32), half_extent=np.ones((2, 3), np.float32))
+    for _ in range(60):
+        w.update(DT)
+        lin, _ = w.get_velocities()
+        assert abs(float(lin[0, 0]) + float(lin[1, 0])) < 1e-5  # total momentum stays zero
+    pos, _ = w.get_transforms()
+    assert pos[1, 0] - pos[0, 0] >= 2.0 - 0.05  # they did not pass through each other
+    lin, _ = w.get_velocities()
+    assert abs(lin[0, 0]) < 0.3  # inelastic: approach velocity removed
+
+
+def test_colouring_is_proper_and_order_independent():
+    sc = scenes.c3(6, 5, 6)
+    w = ob.OracleWorld(sc.config(), trig=ob.TRIG_DET)
+    sc.populate(w)
+    w.update_n(DT, 120)
+    ids, counts, _, _ = w.get_manifolds()
+    colors = w.get_colors()
+    assert len(ids) > 100
+    seen = set()
+    for (a, b), c in zip(ids.tolist(), colors.tolist()):
+        assert (a, c) not in seen
+        seen.add((a, c))
+        if b != GROUND_ID:
+            assert (b, c) not in seen
+            seen.add((b, c))
+    assert colors.max() + 1 == w.get_stats().n_colors
