@@ -216,9 +216,10 @@ float dyn_dot(const std::vector<float>& a, const std::vector<float>& b) {
 }
 
 float dyn_amax(const std::vector<float>& a) {
-    if (a.empty()) return 0.0f;
-    float m = fabsf(a[0]);
-    for (size_t k = 1; k < a.size(); ++k) {
+    // nalgebra amax folds f32::max over |e|, which ignores a NaN operand; starting from 0 is the same
+    // value for every input that is not all-NaN (NaN outcomes are undefined, never tested)
+    float m = 0.0f;
+    for (size_t k = 0; k < a.size(); ++k) {
         const float e = fabsf(a[k]);
         m = (e > m) ? e : m;
     }

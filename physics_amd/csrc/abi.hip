@@ -99,7 +99,7 @@ int32_t phys_destroy(phys_world* w) {
     DevBuf<uint32_t>* ub[] = {&w->shape, &w->global_id, &w->cg_status, &w->cell_xyz, &w->bucket_of, &w->bucket_count,
                               &w->bucket_start, &w->bucket_cursor, &w->sorted_ids, &w->scan_block_sums, &w->pairs,
                               &w->man_a, &w->man_b, &w->man_count, &w->man_color, &w->row_a, &w->row_b, &w->row_count,
-                              &w->row_src, &w->cross_pairs, &w->man_slot, &w->color_block_hist};
+                              &w->row_src, &w->cross_pairs, &w->man_slot, &w->color_block_hist, &w->cg_cols};
     for (auto* b : ub) b->free();
     w->pair_keys.free(); w->man_prio.free(); w->body_top.free(); w->body_used.free();
     w->d_constraints.free(); w->counters.free();
@@ -341,7 +341,9 @@ int32_t phys_get_lambda(phys_world* w, float* lambda_out, uint64_t cap, uint64_t
     ENTER(w);
     if (!n_rows) return fail(PHYS_ERR_INVALID_ARG, "null n_rows");
     PHYS_HIP_TRY(hipStreamSynchronize(w->stream));
-    const uint64_t rows = w->have_lambda ? 3 * (uint64_t)w->constraints.size() : 0;
+    uint32_t st[4] = {0, 0, 0, 0};
+    if (w->cg_status.p && !w->constraints_dirty) PHYS_HIP_TRY(hipMemcpy(st, w->cg_status.p, 16, hipMemcpyDeviceToHost));
+    const uint64_t rows = st[2] ? 3 * (uint64_t)w->constraints.size() : 0;  // previous_solution: Option
     *n_rows = rows;
     if (lambda_out && rows) {
         const uint64_t m = rows < cap ? rows : cap;
@@ -412,13 +414,14 @@ int32_t phys_get_stats(phys_world* w, phys_stats* out) {
     out->n_contacts = c.n_contacts;
     out->n_colors = c.n_colors;
     out->color_rounds = c.color_rounds;
-    if (w->cg_status.p) {
+    if (w->cg_status.p && !w->constraints.empty()) {
         uint32_t st[2] = {1, 0};
         PHYS_HIP_TRY(hipMemcpy(st, w->cg_status.p, 8, hipMemcpyDeviceToHost));
         out->cg_converged = (int32_t)st[0];
         out->cg_iterations = st[1];
     } else {
-        out->cg_converged = 1;
+        out->cg_converged = 1;  // quirk Q8: CG on the empty system returns Some(empty) on its first check
+        out->cg_iterations = w->steps ? 1u : 0u;
     }
     out->steps = w->steps;
     out->overflow = c.overflow;

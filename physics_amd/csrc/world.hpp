@@ -135,7 +135,9 @@ struct phys_world {
     bool constraints_dirty = false;
     bool have_lambda = false;  // previous_solution.is_some()
     phys::DevBuf<float> cg_x, cg_r, cg_p, cg_ap, cg_rhs, cg_c, cg_scratch;
-    phys::DevBuf<uint32_t> cg_status;  // [0] converged flag, [1] iterations
+    phys::DevBuf<uint32_t> cg_status;  // [0] converged flag, [1] iterations, [2] previous_solution.is_some()
+    phys::DevBuf<uint32_t> cg_cols;    // col_id | col_ptr | col_rows | row_cidx (constraints.hip)
+    uint32_t cg_n_cols = 0;
     uint32_t last_cg_iterations = 0;
     int32_t last_cg_converged = 1;
 
