@@ -84,6 +84,8 @@ typedef struct phys_stats {
     uint64_t steps;         /* updates since creation */
     uint32_t overflow;      /* sticky capacity overflow flags */
     uint32_t n_ground_manifolds; /* manifolds against the ground plane (subset of n_manifolds) */
+    float max_extent;       /* largest fattened-AABB edge of the last broad phase (the grid cell is 1.001x this) */
+    uint32_t reserved;
 } phys_stats;
 
 /* reference defaults (see phys_config field comments) */
@@ -187,12 +189,13 @@ int32_t phys_get_device_view(phys_world* w, phys_device_view* out);
 
 /* Sharded broad-phase. Each rank owns the bodies it was given; a halo record is
  * 32 B: {min xyz, max xyz, global id, pad}. phys_halo_pack writes to DEVICE memory the records of
- * owned bodies whose fattened AABB reaches outside [x_lo + reach, x_hi - reach] (reach = one grid
- * cell), returns the count. phys_halo_pairs takes the gathered records of the OTHER ranks (device
+ * owned bodies whose fattened AABB reaches outside [x_lo + reach, x_hi - reach] and returns the count;
+ * reach must be >= the largest AABB edge on ANY rank (all-reduce phys_stats.max_extent), reach <= 0
+ * means this rank's own grid cell. Both calls use the AABBs / grid of the last update or phys_broadphase. phys_halo_pairs takes the gathered records of the OTHER ranks (device
  * memory) and appends owned-vs-remote candidate pairs (local index, global id of the remote body)
  * under the ownership rule "emitted by the rank owning the body with the smaller global id". */
 int32_t phys_set_global_ids(phys_world* w, const uint32_t* global_ids /*n*/);
-int32_t phys_halo_pack(phys_world* w, float x_lo, float x_hi, void* dev_records_out, uint64_t cap,
+int32_t phys_halo_pack(phys_world* w, float x_lo, float x_hi, float reach, void* dev_records_out, uint64_t cap,
                        uint64_t* n_records);
 int32_t phys_halo_pairs(phys_world* w, const void* dev_remote_records, uint64_t n_remote,
                         uint64_t* n_cross_pairs);

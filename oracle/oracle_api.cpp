@@ -2,6 +2,7 @@
 // code. Loaded only by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg
 // (through oracle/binding.py). Mirrors the argument conventions of include/physics_hip.h so the
 // same seeded inputs can be fed to both.
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <string>
@@ -200,6 +201,9 @@ int32_t oracle_get_stats(oracle_world* w, phys_stats* out) {
     out->cg_iterations = w->state.last_cg_iterations;
     out->cg_converged = w->state.last_cg_converged ? 1 : 0;
     out->steps = w->steps;
+    for (size_t i = 0; i + 5 < w->col.aabb.size(); i += 6)
+        if (w->col.shape_type[i / 6] != PHYS_SHAPE_NONE)
+            for (int k = 0; k < 3; ++k) out->max_extent = std::max(out->max_extent, w->col.aabb[i + 3 + k] - w->col.aabb[i + k]);
     for (const auto& m : w->col.manifolds) out->n_ground_manifolds += (m.b == PHYS_GROUND_ID) ? 1u : 0u;
     return PHYS_OK;
 }

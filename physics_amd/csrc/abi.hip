@@ -126,6 +126,7 @@ int32_t phys_set_bodies(phys_world* w, uint64_t n, const float* pos, const float
     w->forces_dirty = false;
     w->have_lambda = false;  // previous_solution: None
     w->aabbs_valid = false;
+    w->grid_valid = false;
     if (n == 0) return PHYS_OK;
 
     // host staging with RigidBody::new defaults (rigid_body.rs:64-76)
@@ -426,6 +427,7 @@ int32_t phys_get_stats(phys_world* w, phys_stats* out) {
     out->steps = w->steps;
     out->overflow = c.overflow;
     out->n_ground_manifolds = c.n_ground_manifolds;
+    std::memcpy(&out->max_extent, &c.max_extent_bits, 4);
     return PHYS_OK;
 }
 
@@ -464,9 +466,10 @@ int32_t phys_set_global_ids(phys_world* w, const uint32_t* global_ids) {
     return PHYS_OK;
 }
 
-int32_t phys_halo_pack(phys_world* w, float x_lo, float x_hi, void* dev_records_out, uint64_t cap, uint64_t* n_records) {
+int32_t phys_halo_pack(phys_world* w, float x_lo, float x_hi, float reach, void* dev_records_out, uint64_t cap,
+                       uint64_t* n_records) {
     ENTER(w);
-    return halo_pack(w, x_lo, x_hi, dev_records_out, cap, n_records);
+    return halo_pack(w, x_lo, x_hi, reach, dev_records_out, cap, n_records);
 }
 int32_t phys_halo_pairs(phys_world* w, const void* dev_remote_records, uint64_t n_remote, uint64_t* n_cross_pairs) {
     ENTER(w);

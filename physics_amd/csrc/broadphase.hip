@@ -306,6 +306,7 @@ int32_t collision_alloc(phys_world* w) {
 void launch_broadphase(phys_world* w) {
     const uint32_t n = (uint32_t)w->n;
     if (n == 0) return;
+    w->grid_valid = true;
     const uint32_t T = w->grid_table_size;
     uint32_t bits = 0;
     while ((1u << (3 * bits)) < T) ++bits;

@@ -123,6 +123,7 @@ struct phys_world {
     bool singular_inertia = false;  // some body's inertia tensor has det == 0 (reference panics in step)
     bool all_diag_inertia = true;
     bool aabbs_valid = false;
+    bool grid_valid = false;  // bucket grid + AABBs of the last broad phase are on the device (halo entry points)
 
     // body SoA
     phys::DevBuf<float> pos, rot, lin, ang, force, torque, mass, inv_mass, inv_inertia, half_extent, aabb;

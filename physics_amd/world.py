@@ -186,9 +186,9 @@ class World:
         ids = np.ascontiguousarray(ids, dtype=np.uint32)
         self._ck(self.lib.phys_set_global_ids(self.h, _p(ids, u32p)))
 
-    def halo_pack(self, x_lo, x_hi, dev_ptr, cap):
+    def halo_pack(self, x_lo, x_hi, reach, dev_ptr, cap):
         n = C.c_uint64()
-        self._ck(self.lib.phys_halo_pack(self.h, x_lo, x_hi, C.c_void_p(dev_ptr), cap, C.byref(n)))
+        self._ck(self.lib.phys_halo_pack(self.h, x_lo, x_hi, reach, C.c_void_p(dev_ptr), cap, C.byref(n)))
         return n.value
 
     def halo_pairs(self, dev_ptr, n_remote):
