@@ -117,6 +117,10 @@ int32_t phys_apply_force_centre_of_gravity(phys_world* w, uint64_t body, const f
 int32_t phys_apply_force_at_position(phys_world* w, uint64_t body, const float force[3], const float point[3]);
 int32_t phys_apply_force_at_offset(phys_world* w, uint64_t body, const float force[3], const float offset[3]);
 
+/* direct writes of body.force / body.torque (pub(crate) fields, rigid_body.rs:12-13): replaces the
+ * accumulators of every body; either pointer may be NULL (= leave that array as it is) */
+int32_t phys_set_forces(phys_world* w, const float* force /*3n*/, const float* torque /*3n*/);
+
 /* PhysicsState::update(&mut self, dt: &Duration) (physics.rs:41-55). dt is passed as whole
  * nanoseconds so Duration::as_secs_f32 (rigid_body.rs:25) is reproduced bit for bit. */
 int32_t phys_update(phys_world* w, uint64_t dt_nanos);

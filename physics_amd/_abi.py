@@ -129,6 +129,7 @@ PROTOTYPES = {
     "phys_apply_force_centre_of_gravity": (C.c_int32, [C.c_void_p, C.c_uint64, f32p]),
     "phys_apply_force_at_position": (C.c_int32, [C.c_void_p, C.c_uint64, f32p, f32p]),
     "phys_apply_force_at_offset": (C.c_int32, [C.c_void_p, C.c_uint64, f32p, f32p]),
+    "phys_set_forces": (C.c_int32, [C.c_void_p, f32p, f32p]),
     "phys_update": (C.c_int32, [C.c_void_p, C.c_uint64]),
     "phys_apply_gravity": (C.c_int32, [C.c_void_p]),
     "phys_step": (C.c_int32, [C.c_void_p, C.c_uint64]),

@@ -219,6 +219,15 @@ int32_t phys_apply_force_at_offset(phys_world* w, uint64_t body, const float for
     return apply_force(w, body, 2, force, offset);
 }
 
+int32_t phys_set_forces(phys_world* w, const float* force, const float* torque) {
+    ENTER(w);
+    if (force) PHYS_HIP_TRY(hipMemcpyAsync(w->force.p, force, 12 * w->n, hipMemcpyHostToDevice, w->stream));
+    if (torque) PHYS_HIP_TRY(hipMemcpyAsync(w->torque.p, torque, 12 * w->n, hipMemcpyHostToDevice, w->stream));
+    PHYS_HIP_TRY(hipStreamSynchronize(w->stream));
+    if (force || torque) w->forces_dirty = true;
+    return PHYS_OK;
+}
+
 int32_t phys_apply_gravity(phys_world* w) {
     ENTER(w);
     launch_apply_gravity(w);

@@ -88,6 +88,10 @@ class World:
         f, o = _f(force), _f(offset)
         self._ck(self.lib.phys_apply_force_at_offset(self.h, body, _p(f), _p(o)))
 
+    def set_forces(self, force=None, torque=None):
+        f, t = _f(force), _f(torque)
+        self._ck(self.lib.phys_set_forces(self.h, _p(f), _p(t)))
+
     # ---- stepping
     def apply_gravity(self):
         self._ck(self.lib.phys_apply_gravity(self.h))
