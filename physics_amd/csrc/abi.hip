@@ -101,7 +101,7 @@ int32_t phys_destroy(phys_world* w) {
                               &w->man_a, &w->man_b, &w->man_count, &w->man_color, &w->row_a, &w->row_b, &w->row_count,
                               &w->row_src, &w->cross_pairs, &w->man_slot, &w->color_block_hist, &w->cg_cols};
     for (auto* b : ub) b->free();
-    w->pair_keys.free(); w->man_prio.free(); w->body_top.free(); w->body_used.free();
+    w->pair_keys.free(); w->man_prio.free(); w->color_state.free();
     w->d_constraints.free(); w->counters.free();
     w->prof.destroy();
     if (w->h_counters) (void)hipHostFree(w->h_counters);

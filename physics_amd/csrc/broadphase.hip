@@ -292,7 +292,7 @@ int32_t collision_alloc(phys_world* w) {
         PHYS_HIP_TRY(w->man_color.resize(M)); PHYS_HIP_TRY(w->man_slot.resize(M));
         PHYS_HIP_TRY(w->man_normal.resize(3 * M)); PHYS_HIP_TRY(w->man_points.resize(16 * M));
         PHYS_HIP_TRY(w->man_prio.resize(M));
-        PHYS_HIP_TRY(w->body_top.resize(2 * n)); PHYS_HIP_TRY(w->body_used.resize(n));
+        PHYS_HIP_TRY(w->color_state.resize(4 * n));
         PHYS_HIP_TRY(w->row_src.resize(M));
         PHYS_HIP_TRY(w->color_block_hist.resize((size_t)kMaxColors * 512));
         PHYS_HIP_TRY(w->row_a.resize(M)); PHYS_HIP_TRY(w->row_b.resize(M)); PHYS_HIP_TRY(w->row_count.resize(M));

@@ -32,7 +32,8 @@ __global__ __launch_bounds__(kNpThreads) void k_narrowphase(
     const float* __restrict__ half_extent, const uint32_t* __restrict__ shape, float margin, float ground,
     uint64_t max_manifolds, uint32_t* __restrict__ man_a, uint32_t* __restrict__ man_b,
     uint32_t* __restrict__ man_count, uint32_t* __restrict__ man_color, float* __restrict__ man_normal,
-    float* __restrict__ man_points, uint64_t* __restrict__ man_prio, StepCounters* __restrict__ ctr) {
+    float* __restrict__ man_points, uint64_t* __restrict__ man_prio, unsigned long long* __restrict__ top0,
+    StepCounters* __restrict__ ctr) {
     __shared__ uint32_t wcount[kNpThreads / 64], wpts[kNpThreads / 64], wground[kNpThreads / 64];
     __shared__ uint32_t block_base;
     const uint32_t np_raw = ctr->n_pairs;
@@ -96,7 +97,11 @@ __global__ __launch_bounds__(kNpThreads) void k_narrowphase(
                 man_b[slot] = b;
                 man_count[slot] = (uint32_t)m.count;
                 man_color[slot] = kUncolored;
-                man_prio[slot] = color_priority(a, b);
+                const unsigned long long prio = color_priority(a, b);
+                man_prio[slot] = prio;
+                // round 0 of the colouring: per-body maximum priority (order-independent u64 max)
+                atomicMax(&top0[a], prio);
+                if (b != PHYS_GROUND_ID) atomicMax(&top0[b], prio);
                 st3(man_normal, (uint32_t)slot, m.normal);
                 float4* o = reinterpret_cast<float4*>(man_points) + 4 * slot;
 #pragma unroll
@@ -113,36 +118,26 @@ __device__ __forceinline__ uint32_t stored_manifolds(const StepCounters* ctr, ui
     return (uint64_t)m < max_manifolds ? m : (uint32_t)max_manifolds;
 }
 
-__global__ __launch_bounds__(1024) void k_color_top(uint64_t max_manifolds, const uint32_t* __restrict__ man_a,
-                                                   const uint32_t* __restrict__ man_b,
-                                                   const uint32_t* __restrict__ man_color,
-                                                   const uint64_t* __restrict__ man_prio,
-                                                   unsigned long long* __restrict__ top,
-                                                   StepCounters* __restrict__ ctr) {
-    if (ctr->n_uncolored == 0) return;
-    if (blockIdx.x == 0 && threadIdx.x == 0) ctr->color_rounds += 1;
-    const uint32_t M = stored_manifolds(ctr, max_manifolds);
-    for (uint32_t m = blockIdx.x * blockDim.x + threadIdx.x; m < M; m += gridDim.x * blockDim.x) {
-        if (man_color[m] != kUncolored) continue;
-        const unsigned long long p = man_prio[m];
-        atomicMax(&top[man_a[m]], p);
-        const uint32_t b = man_b[m];
-        if (b != PHYS_GROUND_ID) atomicMax(&top[b], p);
-    }
-}
-
 constexpr int kColorThreads = 1024;
 
-__global__ __launch_bounds__(kColorThreads) void k_color_assign(uint64_t max_manifolds, const uint32_t* __restrict__ man_a,
-                                                               const uint32_t* __restrict__ man_b,
-                                                               uint32_t* __restrict__ man_color,
-                                                               const uint64_t* __restrict__ man_prio,
-                                                               const unsigned long long* __restrict__ top,
-                                                               unsigned long long* __restrict__ top_next,
-                                                               unsigned long long* __restrict__ used,
-                                                               StepCounters* __restrict__ ctr) {
+// One synchronous Jones-Plassmann round in ONE launch. Three per-body priority buffers rotate:
+//   top      (read)   maxima over the manifolds uncoloured at the start of this round - complete;
+//   top_next (atomic) losers of this round = exactly the manifolds uncoloured at the start of the next
+//                     round publish their priority there (it was cleared one round ago);
+//   top_clr  (store)  the buffer read one round ago, cleared at the losers' bodies for the round after next.
+// Round 0's `top` is filled by k_narrowphase at emission time.
+__global__ __launch_bounds__(kColorThreads) void k_color_round(uint32_t round, uint64_t max_manifolds,
+                                                              const uint32_t* __restrict__ man_a,
+                                                              const uint32_t* __restrict__ man_b,
+                                                              uint32_t* __restrict__ man_color,
+                                                              const uint64_t* __restrict__ man_prio,
+                                                              const unsigned long long* __restrict__ top,
+                                                              unsigned long long* __restrict__ top_next,
+                                                              unsigned long long* __restrict__ top_clr,
+                                                              unsigned long long* __restrict__ used,
+                                                              StepCounters* __restrict__ ctr) {
     // block-uniform early exit (other workgroups decrement n_uncolored while this one starts, so every
-    // thread must act on the SAME read: a barrier follows)
+    // thread must act on the SAME read: a barrier follows). A stale non-zero read costs an idle pass.
     __shared__ uint32_t s_uncolored;
     __shared__ uint32_t s_wins[kColorThreads / 64];
     if (threadIdx.x == 0) s_uncolored = ctr->n_uncolored;
@@ -167,8 +162,9 @@ __global__ __launch_bounds__(kColorThreads) void k_color_assign(uint64_t max_man
             man_color[m] = c;
             ++wins;
         } else {
-            top_next[a] = 0ull;  // losers clear the other buffer for the next round
-            if (!gb) top_next[b] = 0ull;
+            atomicMax(&top_next[a], p);
+            top_clr[a] = 0ull;
+            if (!gb) { atomicMax(&top_next[b], p); top_clr[b] = 0ull; }
         }
     }
     // ONE global atomic per workgroup (same-address atomics serialise chip-wide at ~88 per microsecond)
@@ -179,7 +175,12 @@ __global__ __launch_bounds__(kColorThreads) void k_color_assign(uint64_t max_man
     if (threadIdx.x == 0) {
         uint32_t t = 0;
         for (int k = 0; k < kColorThreads / 64; ++k) t += s_wins[k];
-        if (t) atomicSub(&ctr->n_uncolored, t);
+        if (t) {
+            atomicSub(&ctr->n_uncolored, t);
+            // rounds used = index of the last round that coloured something + 1 (every round with an
+            // uncoloured manifold colours at least the one of highest priority)
+            if (round + 1 > ctr->color_rounds) atomicMax(&ctr->color_rounds, round + 1);
+        }
     }
 }
 
@@ -283,19 +284,22 @@ void launch_narrowphase(phys_world* w) {
     const uint64_t work = (uint64_t)n_ground + w->max_pairs;
     uint64_t blocks = (work + kNpThreads - 1) / kNpThreads;
     if (blocks > 256 * 16) blocks = 256 * 16;
+    // colouring state of the step: used masks + three rotating priority buffers (one memset); the narrow
+    // phase publishes round 0's per-body maxima as it emits manifolds
+    { PHYS_PROF(w, PHYS_STAGE_COLOR); (void)hipMemsetAsync(w->color_state.p, 0, (size_t)4 * n * 8, w->stream); }
     { PHYS_PROF(w, PHYS_STAGE_NARROW); hipLaunchKernelGGL(k_narrowphase, dim3((unsigned)blocks), dim3(kNpThreads), 0, w->stream, n_ground, w->pairs.p,
                        w->max_pairs, w->pos.p, w->rot.p, w->half_extent.p, w->shape.p, w->cfg.contact_margin,
                        w->cfg.ground_height, w->max_manifolds, w->man_a.p, w->man_b.p, w->man_count.p, w->man_color.p,
-                       w->man_normal.p, w->man_points.p, w->man_prio.p, w->counters.p); }
+                       w->man_normal.p, w->man_points.p, w->man_prio.p, w->color_state.p + n, w->counters.p); }
 }
 
 static void launch_color_round(phys_world* w, uint32_t round, unsigned blocks) {
-    unsigned long long* top = w->body_top.p + (round & 1u) * w->n;
-    unsigned long long* top_next = w->body_top.p + ((round + 1u) & 1u) * w->n;
-    { PHYS_PROF(w, PHYS_STAGE_COLOR); hipLaunchKernelGGL(k_color_top, dim3(blocks), dim3(kColorThreads), 0, w->stream, w->max_manifolds, w->man_a.p, w->man_b.p,
-                       w->man_color.p, w->man_prio.p, top, w->counters.p); }
-    { PHYS_PROF(w, PHYS_STAGE_COLOR); hipLaunchKernelGGL(k_color_assign, dim3(blocks), dim3(kColorThreads), 0, w->stream, w->max_manifolds, w->man_a.p, w->man_b.p,
-                       w->man_color.p, w->man_prio.p, top, top_next, w->body_used.p, w->counters.p); }
+    unsigned long long* used = w->color_state.p;
+    unsigned long long* T[3] = {w->color_state.p + w->n, w->color_state.p + 2 * w->n, w->color_state.p + 3 * w->n};
+    PHYS_PROF(w, PHYS_STAGE_COLOR);
+    hipLaunchKernelGGL(k_color_round, dim3(blocks), dim3(kColorThreads), 0, w->stream, round, w->max_manifolds,
+                       w->man_a.p, w->man_b.p, w->man_color.p, w->man_prio.p, T[round % 3], T[(round + 1) % 3],
+                       T[(round + 2) % 3], used, w->counters.p);
 }
 
 // Runs colouring rounds until the device reports no uncoloured manifold, then the counting sort by colour;
@@ -306,8 +310,6 @@ void launch_coloring(phys_world* w) {
     const uint64_t n = w->n;
     if (n == 0) return;
     hipStream_t s = w->stream;
-    { PHYS_PROF(w, PHYS_STAGE_COLOR); (void)hipMemsetAsync(w->body_used.p, 0, n * 8, s); }
-    { PHYS_PROF(w, PHYS_STAGE_COLOR); (void)hipMemsetAsync(w->body_top.p, 0, 2 * n * 8, s); }
     uint64_t blocks64 = (w->max_manifolds + kColorThreads - 1) / kColorThreads;
     if (blocks64 > 512) blocks64 = 512;
     const unsigned blocks = (unsigned)blocks64;

@@ -82,18 +82,13 @@ __global__ __launch_bounds__(256) void k_rows_build(uint32_t M, uint64_t cap, so
     }
 }
 
-// one colour of one iteration: rows [start, start + count)
-__global__ __launch_bounds__(256) void k_solve_color(uint32_t start, uint32_t count, uint64_t cap, float friction,
-                                                     const uint32_t* __restrict__ row_a, const uint32_t* __restrict__ row_b,
-                                                     const uint32_t* __restrict__ row_count,
-                                                     const float* __restrict__ row_normal,
-                                                     const float* __restrict__ row_data, float* __restrict__ row_acc,
-                                                     const float* __restrict__ inv_mass,
-                                                     const float* __restrict__ inv_inertia, float* __restrict__ lin,
-                                                     float* __restrict__ ang) {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= count) return;
-    const uint32_t d = start + t;
+// one manifold row d of the colour-major numbering: load, solve_manifold, store
+__device__ __forceinline__ void solve_row(uint32_t d, uint64_t cap, float friction, const uint32_t* __restrict__ row_a,
+                                          const uint32_t* __restrict__ row_b, const uint32_t* __restrict__ row_count,
+                                          const float* __restrict__ row_normal, const float* __restrict__ row_data,
+                                          float* __restrict__ row_acc, const float* __restrict__ inv_mass,
+                                          const float* __restrict__ inv_inertia, float* __restrict__ lin,
+                                          float* __restrict__ ang) {
     const uint32_t a = row_a[d], b = row_b[d];
     solver_manifold_t sm;
     sm.count = (int)row_count[d];
@@ -138,6 +133,43 @@ __global__ __launch_bounds__(256) void k_solve_color(uint32_t start, uint32_t co
     }
 }
 
+// one colour of one iteration: rows [start, start + count)
+__global__ __launch_bounds__(256) void k_solve_color(uint32_t start, uint32_t count, uint64_t cap, float friction,
+                                                     const uint32_t* __restrict__ row_a, const uint32_t* __restrict__ row_b,
+                                                     const uint32_t* __restrict__ row_count,
+                                                     const float* __restrict__ row_normal,
+                                                     const float* __restrict__ row_data, float* __restrict__ row_acc,
+                                                     const float* __restrict__ inv_mass,
+                                                     const float* __restrict__ inv_inertia, float* __restrict__ lin,
+                                                     float* __restrict__ ang) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= count) return;
+    solve_row(start + t, cap, friction, row_a, row_b, row_count, row_normal, row_data, row_acc, inv_mass, inv_inertia, lin, ang);
+}
+
+// The small colour classes [first, last) of one iteration in ONE launch of ONE workgroup: colours in
+// ascending order with a workgroup barrier between them (all waves share this CU's L1, so a barrier orders
+// the body-velocity writes of one colour before the reads of the next). Same order of work as one launch per
+// colour, without paying a ~8 us launch boundary for a few hundred manifolds.
+constexpr int kTailThreads = 512;  // 2 waves per SIMD: the row solve needs ~144 VGPRs, 1024 threads would spill
+__global__ __launch_bounds__(kTailThreads) void k_solve_tail(ColorTable ct, uint32_t first, uint32_t last, uint64_t cap,
+                                                            float friction, const uint32_t* __restrict__ row_a,
+                                                            const uint32_t* __restrict__ row_b,
+                                                            const uint32_t* __restrict__ row_count,
+                                                            const float* __restrict__ row_normal,
+                                                            const float* __restrict__ row_data, float* __restrict__ row_acc,
+                                                            const float* __restrict__ inv_mass,
+                                                            const float* __restrict__ inv_inertia, float* __restrict__ lin,
+                                                            float* __restrict__ ang) {
+    for (uint32_t col = first; col < last; ++col) {
+        const uint32_t start = ct.start[col], end = ct.start[col + 1];
+        for (uint32_t d = start + threadIdx.x; d < end; d += kTailThreads)
+            solve_row(d, cap, friction, row_a, row_b, row_count, row_normal, row_data, row_acc, inv_mass, inv_inertia, lin, ang);
+        __threadfence_block();
+        __syncthreads();
+    }
+}
+
 // uses the counters fetched by launch_coloring (w->h_counters): manifold and colour counts
 void launch_solver(phys_world* w, float dt) {
     const StepCounters& c = *w->h_counters;
@@ -159,14 +191,27 @@ void launch_solver(phys_world* w, float dt) {
     { PHYS_PROF(w, PHYS_STAGE_ROWS); hipLaunchKernelGGL(k_rows_build, gm, tb, 0, s, M, cap, sp, w->row_src.p, w->man_a.p, w->man_b.p, w->man_count.p,
                        w->man_normal.p, w->man_points.p, w->pos.p, w->inv_mass.p, w->inv_inertia.p, w->row_a.p,
                        w->row_b.p, w->row_count.p, w->row_normal.p, w->row_data.p, w->row_acc.p); }
-    for (uint32_t it = 0; it < w->cfg.solver_iterations; ++it)
-        for (uint32_t col = 0; col < ncol; ++col) {
+    // colours [tail_first, ncol) are all small: they go through the single-workgroup tail launch
+    constexpr uint32_t kTailMax = 512;  // manifolds per colour the tail takes: one trip of the workgroup
+    uint32_t tail_first = ncol;
+    while (tail_first > 0 && c.color_count[tail_first - 1] <= kTailMax) --tail_first;
+    if (ncol - tail_first < 2) tail_first = ncol;  // a tail of one colour is just a slower launch
+    for (uint32_t it = 0; it < w->cfg.solver_iterations; ++it) {
+        for (uint32_t col = 0; col < tail_first; ++col) {
             const uint32_t cnt = c.color_count[col];
             if (cnt == 0) continue;
-            { PHYS_PROF(w, PHYS_STAGE_SOLVE); hipLaunchKernelGGL(k_solve_color, dim3((cnt + 255) / 256), tb, 0, s, ct.start[col], cnt, cap, sp.friction,
+            PHYS_PROF(w, PHYS_STAGE_SOLVE);
+            hipLaunchKernelGGL(k_solve_color, dim3((cnt + 255) / 256), tb, 0, s, ct.start[col], cnt, cap, sp.friction,
                                w->row_a.p, w->row_b.p, w->row_count.p, w->row_normal.p, w->row_data.p, w->row_acc.p,
-                               w->inv_mass.p, w->inv_inertia.p, w->lin.p, w->ang.p); }
+                               w->inv_mass.p, w->inv_inertia.p, w->lin.p, w->ang.p);
         }
+        if (tail_first < ncol) {
+            PHYS_PROF(w, PHYS_STAGE_SOLVE);
+            hipLaunchKernelGGL(k_solve_tail, dim3(1), dim3(kTailThreads), 0, s, ct, tail_first, ncol, cap, sp.friction,
+                               w->row_a.p, w->row_b.p, w->row_count.p, w->row_normal.p, w->row_data.p, w->row_acc.p,
+                               w->inv_mass.p, w->inv_inertia.p, w->lin.p, w->ang.p);
+        }
+    }
 }
 
 }  // namespace phys

@@ -161,7 +161,7 @@ struct phys_world {
     phys::DevBuf<uint64_t> man_prio;
     phys::DevBuf<uint32_t> color_block_hist;  // [colour][workgroup] histogram / offsets of the colour sort
     // colouring state
-    phys::DevBuf<unsigned long long> body_top, body_used;
+    phys::DevBuf<unsigned long long> color_state;  // 4n: used masks | three rotating per-body priority buffers
     // solver rows, colour-sorted SoA
     phys::DevBuf<uint32_t> row_a, row_b, row_count, row_src;
     phys::DevBuf<float> row_normal;  // 3 per manifold (SoA planes)
