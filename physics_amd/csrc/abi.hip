@@ -16,6 +16,45 @@ const char* get_error() { return g_error.c_str(); }
 
 using namespace phys;
 
+namespace phys {
+void poll_snapshots(phys_world* w);
+// enqueue an asynchronous copy of the step counters into the next pinned ring slot
+void snapshot_counters_async(phys_world* w) {
+    const uint32_t k = w->snap_next;
+    if (w->snap_pending[k]) {
+        // ring full: the host is kSnapRing steps ahead of the device. Wait for the oldest sample, so the
+        // launch-size hints never lag by more than the ring depth.
+        (void)hipEventSynchronize(w->snap_event[k]);
+        poll_snapshots(w);
+    }
+    if (!w->h_snap[k]) {
+        if (hipHostMalloc((void**)&w->h_snap[k], sizeof(StepCounters), hipHostMallocDefault) != hipSuccess) return;
+        if (hipEventCreateWithFlags(&w->snap_event[k], hipEventDisableTiming) != hipSuccess) return;
+    }
+    (void)hipMemcpyAsync(w->h_snap[k], w->counters.p, sizeof(StepCounters), hipMemcpyDeviceToHost, w->stream);
+    (void)hipEventRecord(w->snap_event[k], w->stream);
+    w->snap_pending[k] = true;
+    w->snap_next = (k + 1) % phys_world::kSnapRing;
+}
+
+// adopt every snapshot whose copy has completed (oldest first, so the newest complete one wins)
+void poll_snapshots(phys_world* w) {
+    for (int i = 0; i < phys_world::kSnapRing; ++i) {
+        const uint32_t k = (w->snap_next + i) % phys_world::kSnapRing;
+        if (!w->snap_pending[k]) continue;
+        if (hipEventQuery(w->snap_event[k]) != hipSuccess) continue;
+        const StepCounters& c = *w->h_snap[k];
+        w->snap_pending[k] = false;
+        if (c.overflow) continue;
+        w->hint.valid = true;
+        w->hint.n_manifolds = c.n_manifolds;
+        w->hint.n_colors = c.n_colors;
+        w->hint.color_rounds = c.color_rounds;
+        for (int q = 0; q < kMaxColors; ++q) w->hint.color_count[q] = c.color_count[q];
+    }
+}
+}  // namespace phys
+
 static int32_t fail(int32_t code, const char* msg) {
     set_error(msg);
     return code;
@@ -104,6 +143,10 @@ int32_t phys_destroy(phys_world* w) {
     w->pair_keys.free(); w->man_prio.free(); w->color_state.free();
     w->d_constraints.free(); w->counters.free();
     w->prof.destroy();
+    for (int k = 0; k < phys_world::kSnapRing; ++k) {
+        if (w->h_snap[k]) (void)hipHostFree(w->h_snap[k]);
+        if (w->snap_event[k]) (void)hipEventDestroy(w->snap_event[k]);
+    }
     if (w->h_counters) (void)hipHostFree(w->h_counters);
     if (w->stream) (void)hipStreamDestroy(w->stream);
     delete w;
@@ -127,6 +170,8 @@ int32_t phys_set_bodies(phys_world* w, uint64_t n, const float* pos, const float
     w->have_lambda = false;  // previous_solution: None
     w->aabbs_valid = false;
     w->grid_valid = false;
+    w->hint = StepHint();
+    for (int k = 0; k < phys_world::kSnapRing; ++k) w->snap_pending[k] = false;  // the stream was synchronised above
     if (n == 0) return PHYS_OK;
 
     // host staging with RigidBody::new defaults (rigid_body.rs:64-76)
@@ -246,6 +291,7 @@ int32_t phys_step(phys_world* w, uint64_t dt_nanos) {
 // one PhysicsState::update (physics.rs:41-55), enqueued without synchronising
 static int32_t enqueue_update(phys_world* w, float dt) {
     const bool collisions = (w->cfg.flags & PHYS_FLAG_COLLISIONS) != 0;
+    if (collisions) poll_snapshots(w);
     const bool have_constraints = !w->constraints.empty();
     bool gravity_pending = true;
     if (have_constraints) {

@@ -47,6 +47,8 @@ int32_t sorted_pairs_to_host(phys_world* w, uint32_t* pairs_out, uint64_t cap, u
 // narrowphase.hip / solver.hip
 void launch_narrowphase(phys_world* w);
 void launch_coloring(phys_world* w);
+void snapshot_counters_async(phys_world* w);  // abi.hip
+void poll_snapshots(phys_world* w);           // abi.hip
 void launch_solver(phys_world* w, float dt);
 
 // constraints.hip

@@ -126,6 +126,62 @@ constexpr int kColorThreads = 1024;
 //                     round publish their priority there (it was cleared one round ago);
 //   top_clr  (store)  the buffer read one round ago, cleared at the losers' bodies for the round after next.
 // Round 0's `top` is filled by k_narrowphase at emission time.
+// body of one round for the manifolds m = first, first + stride, ...; returns this lane's wins
+template <bool BYPASS_L1>
+__device__ __forceinline__ uint32_t color_round_lanes(uint32_t first, uint32_t stride, uint32_t M,
+                                                      const uint32_t* __restrict__ man_a, const uint32_t* __restrict__ man_b,
+                                                      uint32_t* __restrict__ man_color, const uint64_t* __restrict__ man_prio,
+                                                      const unsigned long long* top, unsigned long long* top_next,
+                                                      unsigned long long* top_clr, unsigned long long* used,
+                                                      StepCounters* __restrict__ ctr) {
+    uint32_t wins = 0;
+    for (uint32_t m = first; m < M; m += stride) {
+        if (man_color[m] != kUncolored) continue;
+        const unsigned long long p = man_prio[m];
+        const uint32_t a = man_a[m], b = man_b[m];
+        const bool gb = b == PHYS_GROUND_ID;
+        // BYPASS_L1 (single-launch finish loop): words other waves changed with atomics inside this launch
+        // must come from L2, not from a line this CU cached rounds ago
+        const unsigned long long ta = BYPASS_L1 ? __hip_atomic_load(&top[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : top[a];
+        unsigned long long tb = p;
+        if (!gb) tb = BYPASS_L1 ? __hip_atomic_load(&top[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : top[b];
+        if (ta == p && tb == p) {
+            unsigned long long mask = BYPASS_L1 ? __hip_atomic_load(&used[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : used[a];
+            unsigned long long mb = 0ull;
+            if (!gb) { mb = BYPASS_L1 ? __hip_atomic_load(&used[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : used[b]; }
+            const unsigned long long ma = mask;
+            mask |= mb;
+            uint32_t c = 0;
+            while (c < (uint32_t)(PHYS_MAX_COLORS - 1) && ((mask >> c) & 1ull)) ++c;
+            if (((mask >> c) & 1ull)) atomicOr(&ctr->overflow, 4u);  // more than PHYS_MAX_COLORS at one body
+            // the winner is the only manifold touching a or b that colours this round
+            if (BYPASS_L1) {
+                __hip_atomic_store(&used[a], ma | (1ull << c), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (!gb) __hip_atomic_store(&used[b], mb | (1ull << c), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                used[a] = ma | (1ull << c);
+                if (!gb) used[b] = mb | (1ull << c);
+            }
+            man_color[m] = c;
+            ++wins;
+        } else {
+            atomicMax(&top_next[a], p);
+            if (BYPASS_L1) __hip_atomic_store(&top_clr[a], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else top_clr[a] = 0ull;
+            if (!gb) {
+                atomicMax(&top_next[b], p);
+                if (BYPASS_L1) __hip_atomic_store(&top_clr[b], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else top_clr[b] = 0ull;
+            }
+        }
+    }
+    return wins;
+}
+
+// One synchronous Jones-Plassmann round in ONE launch. Three per-body priority buffers rotate:
+//   top      (read)   maxima over the manifolds uncoloured at the start of this round - complete;
+//   top_next (atomic) losers of this round = exactly the manifolds uncoloured at the start of the next
+//                     round publish their priority there (it was cleared one round ago);
+//   top_clr  (store)  the buffer read one round ago, cleared at the losers' bodies for the round after next.
+// Round 0's `top` is filled by k_narrowphase at emission time.
 __global__ __launch_bounds__(kColorThreads) void k_color_round(uint32_t round, uint64_t max_manifolds,
                                                               const uint32_t* __restrict__ man_a,
                                                               const uint32_t* __restrict__ man_b,
@@ -144,29 +200,8 @@ __global__ __launch_bounds__(kColorThreads) void k_color_round(uint32_t round, u
     __syncthreads();
     if (s_uncolored == 0) return;
     const uint32_t M = stored_manifolds(ctr, max_manifolds);
-    uint32_t wins = 0;
-    for (uint32_t m = blockIdx.x * blockDim.x + threadIdx.x; m < M; m += gridDim.x * blockDim.x) {
-        if (man_color[m] != kUncolored) continue;
-        const unsigned long long p = man_prio[m];
-        const uint32_t a = man_a[m], b = man_b[m];
-        const bool gb = b == PHYS_GROUND_ID;
-        if (top[a] == p && (gb || top[b] == p)) {
-            unsigned long long mask = used[a];
-            if (!gb) mask |= used[b];
-            uint32_t c = 0;
-            while (c < (uint32_t)(PHYS_MAX_COLORS - 1) && ((mask >> c) & 1ull)) ++c;
-            if (((mask >> c) & 1ull)) atomicOr(&ctr->overflow, 4u);  // more than PHYS_MAX_COLORS at one body
-            // the winner is the only manifold touching a or b that colours this round
-            used[a] = used[a] | (1ull << c);
-            if (!gb) used[b] = used[b] | (1ull << c);
-            man_color[m] = c;
-            ++wins;
-        } else {
-            atomicMax(&top_next[a], p);
-            top_clr[a] = 0ull;
-            if (!gb) { atomicMax(&top_next[b], p); top_clr[b] = 0ull; }
-        }
-    }
+    uint32_t wins = color_round_lanes<false>(blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x, M, man_a, man_b,
+                                             man_color, man_prio, top, top_next, top_clr, used, ctr);
     // ONE global atomic per workgroup (same-address atomics serialise chip-wide at ~88 per microsecond)
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) wins += (uint32_t)__shfl_xor((int)wins, off, 64);
@@ -181,6 +216,47 @@ __global__ __launch_bounds__(kColorThreads) void k_color_round(uint32_t round, u
             // uncoloured manifold colours at least the one of highest priority)
             if (round + 1 > ctr->color_rounds) atomicMax(&ctr->color_rounds, round + 1);
         }
+    }
+}
+
+// Runs whatever rounds are still needed after the launched ones, inside ONE workgroup (barrier between
+// rounds), so the host never has to ask the device whether the colouring is complete. Normally the
+// first read of n_uncolored is 0 and the kernel ends at once.
+__global__ __launch_bounds__(kColorThreads) void k_color_finish(uint32_t round, uint64_t max_manifolds,
+                                                               const uint32_t* __restrict__ man_a,
+                                                               const uint32_t* __restrict__ man_b,
+                                                               uint32_t* __restrict__ man_color,
+                                                               const uint64_t* __restrict__ man_prio,
+                                                               unsigned long long* __restrict__ state /*4n*/, uint64_t n,
+                                                               StepCounters* __restrict__ ctr) {
+    __shared__ uint32_t s_left;
+    __shared__ uint32_t s_wins[kColorThreads / 64];
+    const uint32_t M = stored_manifolds(ctr, max_manifolds);
+    if (threadIdx.x == 0) s_left = ctr->n_uncolored;
+    __syncthreads();
+    uint32_t left = s_left;
+    unsigned long long* used = state;
+    while (left != 0 && left <= M) {
+        unsigned long long* top = state + (1 + round % 3) * n;
+        unsigned long long* top_next = state + (1 + (round + 1) % 3) * n;
+        unsigned long long* top_clr = state + (1 + (round + 2) % 3) * n;
+        uint32_t wins = color_round_lanes<true>(threadIdx.x, kColorThreads, M, man_a, man_b, man_color, man_prio, top,
+                                                top_next, top_clr, used, ctr);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) wins += (uint32_t)__shfl_xor((int)wins, off, 64);
+        if ((threadIdx.x & 63) == 0) s_wins[threadIdx.x >> 6] = wins;
+        __threadfence();  // this round's stores and atomics are performed before anyone starts the next
+        __syncthreads();
+        uint32_t t = 0;
+        for (int k = 0; k < kColorThreads / 64; ++k) t += s_wins[k];
+        left -= t;
+        ++round;
+        __syncthreads();
+        if (t == 0) break;  // cannot happen (the highest priority always wins); never spin
+    }
+    if (threadIdx.x == 0 && left != s_left) {
+        ctr->n_uncolored = left;
+        ctr->color_rounds = round;
     }
 }
 
@@ -302,35 +378,28 @@ static void launch_color_round(phys_world* w, uint32_t round, unsigned blocks) {
                        T[(round + 2) % 3], used, w->counters.p);
 }
 
-// Runs colouring rounds until the device reports no uncoloured manifold, then the counting sort by colour;
-// leaves the final counters (manifold count, colour ranges) in w->h_counters for the solver launch sizes.
-// Steady state: ONE host check per step (the round count of the previous step + 1 is launched up front,
-// together with the speculative histogram + offsets).
+// Colouring + colour-major renumbering, entirely device-driven: `rounds` round launches (the previous
+// steps' round count + 2: surplus launches exit at once), one finish launch that completes whatever is
+// left, then histogram / offsets / place. No host check. A snapshot of the counters is copied to pinned
+// memory asynchronously; later steps use it only as a HINT for launch sizes.
 void launch_coloring(phys_world* w) {
     const uint64_t n = w->n;
     if (n == 0) return;
     hipStream_t s = w->stream;
     uint64_t blocks64 = (w->max_manifolds + kColorThreads - 1) / kColorThreads;
     if (blocks64 > 512) blocks64 = 512;
+    if (w->hint.valid) {
+        const uint64_t want = ((uint64_t)w->hint.n_manifolds * 5 / 4 + kColorThreads) / kColorThreads;
+        if (want < blocks64) blocks64 = want ? want : 1;
+    }
     const unsigned blocks = (unsigned)blocks64;
-    uint32_t round = 0;
-    uint32_t batch = w->color_rounds_hint;
-    for (int guard = 0; guard < 64; ++guard) {
-        for (uint32_t k = 0; k < batch; ++k) launch_color_round(w, round++, blocks);
-        { PHYS_PROF(w, PHYS_STAGE_ROWS); hipLaunchKernelGGL(k_color_hist, dim3(kSortBlocks), dim3(1024), 0, s, w->max_manifolds, w->man_color.p, w->color_block_hist.p, w->counters.p); }
-        { PHYS_PROF(w, PHYS_STAGE_ROWS); hipLaunchKernelGGL(k_color_offsets, dim3(1), dim3(1024), 0, s, w->color_block_hist.p, w->counters.p); }
-        (void)hipMemcpyAsync(w->h_counters, w->counters.p, sizeof(StepCounters), hipMemcpyDeviceToHost, s);
-        (void)hipStreamSynchronize(s);
-        if (w->prof.on) w->prof.collect(s);
-        if (w->h_counters->n_uncolored == 0 || w->h_counters->overflow) break;
-        batch = 2;
-    }
-    const uint32_t used_rounds = w->h_counters->color_rounds;
-    w->color_rounds_hint = used_rounds + 1 > 2 ? used_rounds + 1 : 2;
-    if (w->h_counters->n_manifolds && !w->h_counters->overflow) {
-        PHYS_PROF(w, PHYS_STAGE_ROWS);
-        hipLaunchKernelGGL(k_color_place, dim3(kSortBlocks), dim3(1024), 0, s, w->max_manifolds, w->man_color.p, w->color_block_hist.p, w->row_src.p, w->counters.p);
-    }
+    const uint32_t rounds = w->hint.valid ? w->hint.color_rounds + 2 : 10;
+    for (uint32_t r = 0; r < rounds; ++r) launch_color_round(w, r, blocks);
+    { PHYS_PROF(w, PHYS_STAGE_COLOR); hipLaunchKernelGGL(k_color_finish, dim3(1), dim3(kColorThreads), 0, s, rounds, w->max_manifolds, w->man_a.p, w->man_b.p, w->man_color.p, w->man_prio.p, w->color_state.p, (uint64_t)n, w->counters.p); }
+    { PHYS_PROF(w, PHYS_STAGE_ROWS); hipLaunchKernelGGL(k_color_hist, dim3(kSortBlocks), dim3(1024), 0, s, w->max_manifolds, w->man_color.p, w->color_block_hist.p, w->counters.p); }
+    { PHYS_PROF(w, PHYS_STAGE_ROWS); hipLaunchKernelGGL(k_color_offsets, dim3(1), dim3(1024), 0, s, w->color_block_hist.p, w->counters.p); }
+    { PHYS_PROF(w, PHYS_STAGE_ROWS); hipLaunchKernelGGL(k_color_place, dim3(kSortBlocks), dim3(1024), 0, s, w->max_manifolds, w->man_color.p, w->color_block_hist.p, w->row_src.p, w->counters.p); }
+    snapshot_counters_async(w);
 }
 
 }  // namespace phys

@@ -30,7 +30,7 @@ __device__ __forceinline__ m33 ld_m33(const float* __restrict__ p, uint32_t i) {
     return M;
 }
 
-__global__ __launch_bounds__(256) void k_rows_build(uint32_t M, uint64_t cap, solve_params_t sp,
+__global__ __launch_bounds__(256) void k_rows_build(const StepCounters* __restrict__ ctr, uint64_t cap, solve_params_t sp,
                                                     const uint32_t* __restrict__ row_src,
                                                     const uint32_t* __restrict__ man_a, const uint32_t* __restrict__ man_b,
                                                     const uint32_t* __restrict__ man_count,
@@ -41,8 +41,9 @@ __global__ __launch_bounds__(256) void k_rows_build(uint32_t M, uint64_t cap, so
                                                     uint32_t* __restrict__ row_b, uint32_t* __restrict__ row_count,
                                                     float* __restrict__ row_normal, float* __restrict__ row_data,
                                                     float* __restrict__ row_acc) {
-    const uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
-    if (d >= M) return;
+    if (ctr->overflow) return;  // never solve a truncated set; phys_sync / phys_get_stats report it
+    const uint32_t M = ctr->n_manifolds;
+    for (uint32_t d = blockIdx.x * blockDim.x + threadIdx.x; d < M; d += gridDim.x * blockDim.x) {
     const uint32_t m = row_src[d];
     manifold_t g;
     const uint32_t a = man_a[m], b = man_b[m];
@@ -79,6 +80,7 @@ __global__ __launch_bounds__(256) void k_rows_build(uint32_t M, uint64_t cap, so
             float* acc = row_acc + (size_t)(k * kAccPlanesPerPoint) * cap + d;
             acc[0 * cap] = 0.0f; acc[1 * cap] = 0.0f; acc[2 * cap] = 0.0f;
         }
+    }
     }
 }
 
@@ -133,26 +135,29 @@ __device__ __forceinline__ void solve_row(uint32_t d, uint64_t cap, float fricti
     }
 }
 
-// one colour of one iteration: rows [start, start + count)
-__global__ __launch_bounds__(256) void k_solve_color(uint32_t start, uint32_t count, uint64_t cap, float friction,
-                                                     const uint32_t* __restrict__ row_a, const uint32_t* __restrict__ row_b,
+// one colour of one iteration; the row range comes from the device-side colour table
+__global__ __launch_bounds__(256) void k_solve_color(const StepCounters* __restrict__ ctr, uint32_t col, uint64_t cap,
+                                                     float friction, const uint32_t* __restrict__ row_a,
+                                                     const uint32_t* __restrict__ row_b,
                                                      const uint32_t* __restrict__ row_count,
                                                      const float* __restrict__ row_normal,
                                                      const float* __restrict__ row_data, float* __restrict__ row_acc,
                                                      const float* __restrict__ inv_mass,
                                                      const float* __restrict__ inv_inertia, float* __restrict__ lin,
                                                      float* __restrict__ ang) {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= count) return;
-    solve_row(start + t, cap, friction, row_a, row_b, row_count, row_normal, row_data, row_acc, inv_mass, inv_inertia, lin, ang);
+    if (ctr->overflow) return;
+    const uint32_t start = ctr->color_start[col], end = ctr->color_start[col + 1];
+    for (uint32_t d = start + blockIdx.x * blockDim.x + threadIdx.x; d < end; d += gridDim.x * blockDim.x)
+        solve_row(d, cap, friction, row_a, row_b, row_count, row_normal, row_data, row_acc, inv_mass, inv_inertia, lin, ang);
 }
 
-// The small colour classes [first, last) of one iteration in ONE launch of ONE workgroup: colours in
+// The colour classes [first, n_colours) of one iteration in ONE launch of ONE workgroup: colours in
 // ascending order with a workgroup barrier between them (all waves share this CU's L1, so a barrier orders
 // the body-velocity writes of one colour before the reads of the next). Same order of work as one launch per
-// colour, without paying a ~8 us launch boundary for a few hundred manifolds.
+// colour, without paying a ~8 us launch for a few hundred manifolds. `first` is a host HINT (the small
+// colours of the previous step); any value gives the same result, only the speed changes.
 constexpr int kTailThreads = 512;  // 2 waves per SIMD: the row solve needs ~144 VGPRs, 1024 threads would spill
-__global__ __launch_bounds__(kTailThreads) void k_solve_tail(ColorTable ct, uint32_t first, uint32_t last, uint64_t cap,
+__global__ __launch_bounds__(kTailThreads) void k_solve_tail(const StepCounters* __restrict__ ctr, uint32_t first, uint64_t cap,
                                                             float friction, const uint32_t* __restrict__ row_a,
                                                             const uint32_t* __restrict__ row_b,
                                                             const uint32_t* __restrict__ row_count,
@@ -161,8 +166,10 @@ __global__ __launch_bounds__(kTailThreads) void k_solve_tail(ColorTable ct, uint
                                                             const float* __restrict__ inv_mass,
                                                             const float* __restrict__ inv_inertia, float* __restrict__ lin,
                                                             float* __restrict__ ang) {
+    if (ctr->overflow) return;
+    const uint32_t last = ctr->n_colors;
     for (uint32_t col = first; col < last; ++col) {
-        const uint32_t start = ct.start[col], end = ct.start[col + 1];
+        const uint32_t start = ctr->color_start[col], end = ctr->color_start[col + 1];
         for (uint32_t d = start + threadIdx.x; d < end; d += kTailThreads)
             solve_row(d, cap, friction, row_a, row_b, row_count, row_normal, row_data, row_acc, inv_mass, inv_inertia, lin, ang);
         __threadfence_block();
@@ -170,15 +177,11 @@ __global__ __launch_bounds__(kTailThreads) void k_solve_tail(ColorTable ct, uint
     }
 }
 
-// uses the counters fetched by launch_coloring (w->h_counters): manifold and colour counts
+// Launch sizes come from the HINT (counters of an earlier step, read back asynchronously); every kernel
+// takes its real ranges from the device-side counters, so a stale hint costs speed, never correctness.
 void launch_solver(phys_world* w, float dt) {
-    const StepCounters& c = *w->h_counters;
-    if (c.overflow) return;  // reported by phys_sync / phys_get_stats; never solve a truncated set
-    const uint32_t M = c.n_manifolds;
-    if (M == 0 || w->n == 0) return;
-    const uint32_t ncol = c.n_colors;
-    ColorTable ct;
-    for (uint32_t k = 0; k <= (uint32_t)kMaxColors; ++k) ct.start[k] = c.color_start[k];  // from k_color_offsets
+    if (w->n == 0) return;
+    const StepHint& h = w->hint;
     solve_params_t sp;
     sp.dt = dt;
     sp.baumgarte = w->cfg.baumgarte;
@@ -187,30 +190,37 @@ void launch_solver(phys_world* w, float dt) {
     sp.max_bias = w->cfg.max_bias;
     hipStream_t s = w->stream;
     const uint64_t cap = w->max_manifolds;
-    const dim3 gm((M + 255) / 256), tb(256);
-    { PHYS_PROF(w, PHYS_STAGE_ROWS); hipLaunchKernelGGL(k_rows_build, gm, tb, 0, s, M, cap, sp, w->row_src.p, w->man_a.p, w->man_b.p, w->man_count.p,
+    const dim3 tb(256);
+    auto grid_for_count = [&](uint64_t count) {
+        uint64_t b = (count * 5 / 4 + 255) / 256 + 1;
+        const uint64_t hi = (cap + 255) / 256;
+        if (b > hi) b = hi;
+        if (b > 4096) b = 4096;
+        return dim3((unsigned)(b ? b : 1));
+    };
+    const uint64_t m_hint = h.valid ? h.n_manifolds : cap;
+    { PHYS_PROF(w, PHYS_STAGE_ROWS); hipLaunchKernelGGL(k_rows_build, grid_for_count(m_hint), tb, 0, s, w->counters.p, cap, sp, w->row_src.p, w->man_a.p, w->man_b.p, w->man_count.p,
                        w->man_normal.p, w->man_points.p, w->pos.p, w->inv_mass.p, w->inv_inertia.p, w->row_a.p,
                        w->row_b.p, w->row_count.p, w->row_normal.p, w->row_data.p, w->row_acc.p); }
-    // colours [tail_first, ncol) are all small: they go through the single-workgroup tail launch
-    constexpr uint32_t kTailMax = 512;  // manifolds per colour the tail takes: one trip of the workgroup
-    uint32_t tail_first = ncol;
-    while (tail_first > 0 && c.color_count[tail_first - 1] <= kTailMax) --tail_first;
-    if (ncol - tail_first < 2) tail_first = ncol;  // a tail of one colour is just a slower launch
+    // colours [0, big) get a launch each; [big, n_colours) go through the single-workgroup tail
+    constexpr uint32_t kTailMax = 512;  // manifolds per colour the tail should take: one trip of the workgroup
+    uint32_t big = 0;
+    if (h.valid) {
+        big = h.n_colors;
+        while (big > 0 && h.color_count[big - 1] <= kTailMax) --big;
+        if (h.n_colors - big < 2) big = h.n_colors;  // a tail of one colour is just a slower launch
+    }
     for (uint32_t it = 0; it < w->cfg.solver_iterations; ++it) {
-        for (uint32_t col = 0; col < tail_first; ++col) {
-            const uint32_t cnt = c.color_count[col];
-            if (cnt == 0) continue;
+        for (uint32_t col = 0; col < big; ++col) {
             PHYS_PROF(w, PHYS_STAGE_SOLVE);
-            hipLaunchKernelGGL(k_solve_color, dim3((cnt + 255) / 256), tb, 0, s, ct.start[col], cnt, cap, sp.friction,
+            hipLaunchKernelGGL(k_solve_color, grid_for_count(h.color_count[col]), tb, 0, s, w->counters.p, col, cap, sp.friction,
                                w->row_a.p, w->row_b.p, w->row_count.p, w->row_normal.p, w->row_data.p, w->row_acc.p,
                                w->inv_mass.p, w->inv_inertia.p, w->lin.p, w->ang.p);
         }
-        if (tail_first < ncol) {
-            PHYS_PROF(w, PHYS_STAGE_SOLVE);
-            hipLaunchKernelGGL(k_solve_tail, dim3(1), dim3(kTailThreads), 0, s, ct, tail_first, ncol, cap, sp.friction,
-                               w->row_a.p, w->row_b.p, w->row_count.p, w->row_normal.p, w->row_data.p, w->row_acc.p,
-                               w->inv_mass.p, w->inv_inertia.p, w->lin.p, w->ang.p);
-        }
+        PHYS_PROF(w, PHYS_STAGE_SOLVE);
+        hipLaunchKernelGGL(k_solve_tail, dim3(1), dim3(kTailThreads), 0, s, w->counters.p, big, cap, sp.friction,
+                           w->row_a.p, w->row_b.p, w->row_count.p, w->row_normal.p, w->row_data.p, w->row_acc.p,
+                           w->inv_mass.p, w->inv_inertia.p, w->lin.p, w->ang.p);
     }
 }
 

@@ -105,6 +105,14 @@ struct ProfScope {
     ~ProfScope() { if (p.on) p.end(s); }
 };
 
+// launch-size hints taken from an EARLIER step's counters (asynchronous read-back); never needed for
+// correctness
+struct StepHint {
+    bool valid = false;
+    uint32_t n_manifolds = 0, n_colors = 0, color_rounds = 0;
+    uint32_t color_count[kMaxColors] = {};
+};
+
 struct Constraint {
     uint32_t kind;  // 0 fix point, 1 fix orientation
     uint32_t body;
@@ -171,7 +179,12 @@ struct phys_world {
     phys::DevBuf<uint32_t> cross_pairs;
     uint64_t max_cross_pairs = 0;
 
-    uint32_t color_rounds_hint = 8;  // colouring rounds launched before the first completion check
+    phys::StepHint hint;
+    static constexpr int kSnapRing = 4;
+    phys::StepCounters* h_snap[kSnapRing] = {};  // pinned snapshots of the counters
+    hipEvent_t snap_event[kSnapRing] = {};
+    bool snap_pending[kSnapRing] = {};
+    uint32_t snap_next = 0;
     phys::Profiler prof;
     phys_stats stats{};
     // pinned host mirror of the counters for read-back
