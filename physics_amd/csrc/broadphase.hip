@@ -142,6 +142,27 @@ __global__ __launch_bounds__(kScanThreads) void k_scan_final(const uint32_t* __r
     }
 }
 
+// small tables: the whole exclusive scan in ONE workgroup (one launch instead of three). Each thread owns
+// one contiguous segment of count/1024 buckets; one barrier.
+__global__ __launch_bounds__(1024) void k_scan_single(const uint32_t* __restrict__ in, uint32_t count,
+                                                      uint32_t* __restrict__ out /*count + 1*/) {
+    __shared__ uint32_t wtot[16];
+    const uint32_t seg = (count + 1023) / 1024;
+    const uint32_t base = threadIdx.x * seg;
+    uint32_t s = 0;
+    for (uint32_t k = 0; k < seg; ++k) s += (base + k < count) ? in[base + k] : 0u;
+    const uint32_t inc = wave_inclusive_scan(s);
+    if ((threadIdx.x & 63) == 63) wtot[threadIdx.x >> 6] = inc;
+    __syncthreads();
+    uint32_t off = 0;
+    for (uint32_t k = 0; k < (threadIdx.x >> 6); ++k) off += wtot[k];
+    uint32_t run = off + inc - s;
+    for (uint32_t k = 0; k < seg; ++k) {
+        if (base + k < count) { out[base + k] = run; run += in[base + k]; }
+    }
+    if (threadIdx.x == 1023) out[count] = run;
+}
+
 // ---- group bodies by bucket -----------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_scatter(uint32_t n, const float* __restrict__ aabb,
                                                  const uint32_t* __restrict__ bucket_of,
@@ -203,22 +224,30 @@ __device__ __forceinline__ void stage_push(PairStage& st, bool hit, uint32_t a, 
     st.count += hits;
 }
 
+// kLanesPerBody lanes share one body: each takes every kLanesPerBody-th cell of the half shell, so the
+// dependent chain per lane (bucket range -> candidate ids/boxes) is a quarter as long and four times as
+// many loads are in flight. The ranges of a lane's cells are fetched up front (independent loads).
+template <int kLanesPerBody>
 __global__ __launch_bounds__(kPairThreads) void k_find_pairs(const uint32_t* __restrict__ bucket_start,
                                                              uint32_t table_size, uint32_t axis_mask,
                                                              const uint32_t* __restrict__ sorted_ids,
                                                              const float* __restrict__ sorted_box,
                                                              uint32_t* __restrict__ pairs, uint64_t max_pairs,
                                                              StepCounters* __restrict__ ctr) {
+    constexpr int kCellsPerLane = (14 + kLanesPerBody - 1) / kLanesPerBody;
     __shared__ uint32_t stage[(kPairThreads / 64) * kStagePerWave * 2];
     PairStage st;
     st.lds = stage + (threadIdx.x >> 6) * kStagePerWave * 2;
     st.count = 0;
     const uint32_t n_active = bucket_start[table_size];
-    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t s = g / kLanesPerBody;
+    const uint32_t sub = g % kLanesPerBody;
     const bool live = s < n_active;
     const float inv_cell = grid_inv_cell(ctr);
     uint32_t i = 0;
     aabb_t bi;
+    bi.lo = v3_make(0, 0, 0); bi.hi = v3_make(0, 0, 0);
     int cx = 0, cy = 0, cz = 0;
     if (live) {
         i = sorted_ids[s];
@@ -228,19 +257,28 @@ __global__ __launch_bounds__(kPairThreads) void k_find_pairs(const uint32_t* __r
         cy = cell_coord(0.5f * (bi.lo.y + bi.hi.y), inv_cell);
         cz = cell_coord(0.5f * (bi.lo.z + bi.hi.z), inv_cell);
     }
-    // half shell: own cell + the 13 cells with (dz, dy, dx) > (0, 0, 0) lexicographically
-    for (int c = 0; c < 14; ++c) {
+    // half shell: own cell (c = 0) + the 13 cells with (dz, dy, dx) > (0, 0, 0) lexicographically
+    uint32_t t0[kCellsPerLane], t1[kCellsPerLane];
+#pragma unroll
+    for (int k = 0; k < kCellsPerLane; ++k) {
+        const int c = (int)sub + kLanesPerBody * k;
         int dx, dy, dz;
         if (c == 0) { dx = 0; dy = 0; dz = 0; }
         else if (c == 1) { dx = 1; dy = 0; dz = 0; }
         else if (c < 5) { dx = c - 3; dy = 1; dz = 0; }
         else { dx = (c - 5) % 3 - 1; dy = ((c - 5) / 3) % 3 - 1; dz = 1; }
-        uint32_t t = 0, t_end = 0;
-        if (live) {
+        t0[k] = 0; t1[k] = 0;
+        if (live && c < 14) {
             const uint32_t bk = bucket_of_cell(cx + dx, cy + dy, cz + dz, axis_mask);
-            t = bucket_start[bk];
-            t_end = bucket_start[bk + 1];
+            t0[k] = bucket_start[bk];
+            t1[k] = bucket_start[bk + 1];
         }
+    }
+#pragma unroll
+    for (int k = 0; k < kCellsPerLane; ++k) {
+        const bool own_cell = (sub == 0 && k == 0);
+        uint32_t t = t0[k];
+        const uint32_t t_end = t1[k];
         while (__any(t < t_end)) {
             bool hit = false;
             uint32_t j = 0;
@@ -251,7 +289,7 @@ __global__ __launch_bounds__(kPairThreads) void k_find_pairs(const uint32_t* __r
                 bj.hi = ld3(sorted_box, 2 * t + 1);
                 // own cell: each unordered pair once by id order. Other cells: a bucket can alias a far cell
                 // (wrap-around); such a candidate fails the overlap test, and the 14 buckets are distinct.
-                hit = aabb_overlap(bi, bj) && (c != 0 || i < j);
+                hit = aabb_overlap(bi, bj) && (!own_cell || i < j);
                 ++t;
             }
             stage_push(st, hit, i < j ? i : j, i < j ? j : i, pairs, max_pairs, ctr);
@@ -316,16 +354,29 @@ void launch_broadphase(phys_world* w) {
     { PHYS_PROF(w, PHYS_STAGE_GRID); (void)hipMemsetAsync(w->bucket_count.p, 0, (size_t)T * 4, s); }
     { PHYS_PROF(w, PHYS_STAGE_GRID); hipLaunchKernelGGL(k_cell_assign, gb, tb, 0, s, n, w->aabb.p, w->shape.p, w->counters.p, axis_mask, w->bucket_of.p,
                        w->bucket_cursor.p, w->bucket_count.p); }
-    const uint32_t nblk = (T + kScanChunk - 1) / kScanChunk;
-    { PHYS_PROF(w, PHYS_STAGE_GRID); hipLaunchKernelGGL(k_scan_reduce, dim3(nblk), dim3(kScanThreads), 0, s, w->bucket_count.p, T, w->scan_block_sums.p); }
-    { PHYS_PROF(w, PHYS_STAGE_GRID); hipLaunchKernelGGL(k_scan_block_sums, dim3(1), dim3(1024), 0, s, w->scan_block_sums.p, nblk); }
-    { PHYS_PROF(w, PHYS_STAGE_GRID); hipLaunchKernelGGL(k_scan_final, dim3(nblk), dim3(kScanThreads), 0, s, w->bucket_count.p, T, w->scan_block_sums.p,
-                       w->bucket_start.p); }
+    if (T <= 1024u) {  // (measured: for T >= 32k the three-kernel scan is faster than one workgroup)
+        PHYS_PROF(w, PHYS_STAGE_GRID);
+        hipLaunchKernelGGL(k_scan_single, dim3(1), dim3(1024), 0, s, w->bucket_count.p, T, w->bucket_start.p);
+    } else {
+        const uint32_t nblk = (T + kScanChunk - 1) / kScanChunk;
+        { PHYS_PROF(w, PHYS_STAGE_GRID); hipLaunchKernelGGL(k_scan_reduce, dim3(nblk), dim3(kScanThreads), 0, s, w->bucket_count.p, T, w->scan_block_sums.p); }
+        { PHYS_PROF(w, PHYS_STAGE_GRID); hipLaunchKernelGGL(k_scan_block_sums, dim3(1), dim3(1024), 0, s, w->scan_block_sums.p, nblk); }
+        { PHYS_PROF(w, PHYS_STAGE_GRID); hipLaunchKernelGGL(k_scan_final, dim3(nblk), dim3(kScanThreads), 0, s, w->bucket_count.p, T, w->scan_block_sums.p,
+                           w->bucket_start.p); }
+    }
     { PHYS_PROF(w, PHYS_STAGE_GRID); hipLaunchKernelGGL(k_scatter, gb, tb, 0, s, n, w->aabb.p, w->bucket_of.p, w->bucket_cursor.p, w->bucket_start.p,
                        w->sorted_ids.p, w->sorted_box.p); }
-    { PHYS_PROF(w, PHYS_STAGE_PAIRS); hipLaunchKernelGGL(k_find_pairs, dim3((n + kPairThreads - 1) / kPairThreads), dim3(kPairThreads), 0, s,
-                       w->bucket_start.p, T, axis_mask, w->sorted_ids.p, w->sorted_box.p, w->pairs.p, w->max_pairs,
-                       w->counters.p); }
+    // small scenes are latency-bound: 4 lanes per body shorten the dependent chain; large scenes are
+    // throughput-bound: one lane per body does the least total work
+    if (n <= 200000u) {
+        PHYS_PROF(w, PHYS_STAGE_PAIRS);
+        hipLaunchKernelGGL((k_find_pairs<4>), dim3((unsigned)(((uint64_t)n * 4 + kPairThreads - 1) / kPairThreads)), dim3(kPairThreads), 0, s,
+                           w->bucket_start.p, T, axis_mask, w->sorted_ids.p, w->sorted_box.p, w->pairs.p, w->max_pairs, w->counters.p);
+    } else {
+        PHYS_PROF(w, PHYS_STAGE_PAIRS);
+        hipLaunchKernelGGL((k_find_pairs<1>), dim3((n + kPairThreads - 1) / kPairThreads), dim3(kPairThreads), 0, s,
+                           w->bucket_start.p, T, axis_mask, w->sorted_ids.p, w->sorted_box.p, w->pairs.p, w->max_pairs, w->counters.p);
+    }
 }
 
 // phys_broadphase read-out: pairs sorted by (i, j). The sort is a host-side convenience of this

@@ -263,11 +263,11 @@ __global__ __launch_bounds__(kColorThreads) void k_color_finish(uint32_t round, 
 // ---- colour-major renumbering: counting sort of the manifolds by colour ---------------------------
 // hist (per-workgroup colour histogram) -> offsets (one workgroup scans colour-major) -> place.
 // No global atomics; the order inside a colour is (workgroup, arrival), which nothing depends on.
-constexpr int kSortBlocks = 512;   // workgroups of the hist / place kernels (fixed, so the scan is small)
+constexpr int kSortBlocksMax = 512;  // most workgroups of the hist / place kernels (the launch picks nb <= this)
 constexpr int kSortChunk = 4096;   // manifolds per workgroup trip
 
 __global__ __launch_bounds__(1024) void k_color_hist(uint64_t max_manifolds, const uint32_t* __restrict__ man_color,
-                                                     uint32_t* __restrict__ block_hist /*[colour][kSortBlocks]*/,
+                                                     uint32_t* __restrict__ block_hist /*[colour][nb]*/, uint32_t nb,
                                                      const StepCounters* __restrict__ ctr) {
     __shared__ uint32_t h[PHYS_MAX_COLORS];
     if (threadIdx.x < PHYS_MAX_COLORS) h[threadIdx.x] = 0;
@@ -284,21 +284,21 @@ __global__ __launch_bounds__(1024) void k_color_hist(uint64_t max_manifolds, con
         }
     }
     __syncthreads();
-    if (threadIdx.x < PHYS_MAX_COLORS) block_hist[threadIdx.x * kSortBlocks + blockIdx.x] = h[threadIdx.x];
+    if (threadIdx.x < PHYS_MAX_COLORS) block_hist[threadIdx.x * nb + blockIdx.x] = h[threadIdx.x];
 }
 
 // one workgroup: exclusive scan of block_hist in colour-major order (in place) + per-colour totals
-__global__ __launch_bounds__(1024) void k_color_offsets(uint32_t* __restrict__ block_hist, StepCounters* __restrict__ ctr) {
+__global__ __launch_bounds__(1024) void k_color_offsets(uint32_t* __restrict__ block_hist, uint32_t nb, StepCounters* __restrict__ ctr) {
     __shared__ uint32_t wtot[16];
     __shared__ uint32_t carry_s;
     if (threadIdx.x == 0) carry_s = 0;
     __syncthreads();
-    constexpr uint32_t kPerColor = kSortBlocks;
-    constexpr uint32_t kTotal = PHYS_MAX_COLORS * kPerColor;
+    const uint32_t kPerColor = nb;
+    const uint32_t kTotal = PHYS_MAX_COLORS * kPerColor;
     uint32_t ncol = 0;
     for (uint32_t base = 0; base < kTotal; base += 1024) {
         const uint32_t idx = base + threadIdx.x;
-        const uint32_t v = block_hist[idx];
+        const uint32_t v = idx < kTotal ? block_hist[idx] : 0u;
         uint32_t inc = v;
         const int lane = threadIdx.x & 63;
 #pragma unroll
@@ -312,8 +312,10 @@ __global__ __launch_bounds__(1024) void k_color_offsets(uint32_t* __restrict__ b
         for (uint32_t k = 0; k < (threadIdx.x >> 6); ++k) woff += wtot[k];
         const uint32_t carry = carry_s;
         const uint32_t excl = carry + woff + inc - v;
-        block_hist[idx] = excl;
-        if (idx % kPerColor == 0) ctr->color_start[idx / kPerColor] = excl;
+        if (idx < kTotal) {
+            block_hist[idx] = excl;
+            if (idx % kPerColor == 0) ctr->color_start[idx / kPerColor] = excl;
+        }
         __syncthreads();
         if (threadIdx.x == 1023) carry_s = carry + woff + inc;
         __syncthreads();
@@ -335,10 +337,10 @@ __global__ __launch_bounds__(1024) void k_color_offsets(uint32_t* __restrict__ b
 }
 
 __global__ __launch_bounds__(1024) void k_color_place(uint64_t max_manifolds, const uint32_t* __restrict__ man_color,
-                                                      const uint32_t* __restrict__ block_off /*scanned block_hist*/,
+                                                      const uint32_t* __restrict__ block_off /*scanned block_hist*/, uint32_t nb,
                                                       uint32_t* __restrict__ row_src, const StepCounters* __restrict__ ctr) {
     __shared__ uint32_t cursor[PHYS_MAX_COLORS];
-    if (threadIdx.x < PHYS_MAX_COLORS) cursor[threadIdx.x] = block_off[threadIdx.x * kSortBlocks + blockIdx.x];
+    if (threadIdx.x < PHYS_MAX_COLORS) cursor[threadIdx.x] = block_off[threadIdx.x * nb + blockIdx.x];
     __syncthreads();
     const uint32_t M = stored_manifolds(ctr, max_manifolds);
     for (uint32_t base = blockIdx.x * kSortChunk; base < M; base += gridDim.x * kSortChunk) {
@@ -393,12 +395,19 @@ void launch_coloring(phys_world* w) {
         if (want < blocks64) blocks64 = want ? want : 1;
     }
     const unsigned blocks = (unsigned)blocks64;
-    const uint32_t rounds = w->hint.valid ? w->hint.color_rounds + 2 : 10;
+    const uint32_t rounds = w->hint.valid ? w->hint.color_rounds + 1 : 10;  // k_color_finish covers a miss
     for (uint32_t r = 0; r < rounds; ++r) launch_color_round(w, r, blocks);
     { PHYS_PROF(w, PHYS_STAGE_COLOR); hipLaunchKernelGGL(k_color_finish, dim3(1), dim3(kColorThreads), 0, s, rounds, w->max_manifolds, w->man_a.p, w->man_b.p, w->man_color.p, w->man_prio.p, w->color_state.p, (uint64_t)n, w->counters.p); }
-    { PHYS_PROF(w, PHYS_STAGE_ROWS); hipLaunchKernelGGL(k_color_hist, dim3(kSortBlocks), dim3(1024), 0, s, w->max_manifolds, w->man_color.p, w->color_block_hist.p, w->counters.p); }
-    { PHYS_PROF(w, PHYS_STAGE_ROWS); hipLaunchKernelGGL(k_color_offsets, dim3(1), dim3(1024), 0, s, w->color_block_hist.p, w->counters.p); }
-    { PHYS_PROF(w, PHYS_STAGE_ROWS); hipLaunchKernelGGL(k_color_place, dim3(kSortBlocks), dim3(1024), 0, s, w->max_manifolds, w->man_color.p, w->color_block_hist.p, w->row_src.p, w->counters.p); }
+    // workgroups of the colour sort: sized from the hint (any value is correct: the kernels stride)
+    uint32_t nb = kSortBlocksMax;
+    if (w->hint.valid) {
+        const uint64_t want = ((uint64_t)w->hint.n_manifolds * 5 / 4) / kSortChunk + 1;
+        nb = 1;
+        while (nb < want && nb < (uint32_t)kSortBlocksMax) nb <<= 1;
+    }
+    { PHYS_PROF(w, PHYS_STAGE_ROWS); hipLaunchKernelGGL(k_color_hist, dim3(nb), dim3(1024), 0, s, w->max_manifolds, w->man_color.p, w->color_block_hist.p, nb, w->counters.p); }
+    { PHYS_PROF(w, PHYS_STAGE_ROWS); hipLaunchKernelGGL(k_color_offsets, dim3(1), dim3(1024), 0, s, w->color_block_hist.p, nb, w->counters.p); }
+    { PHYS_PROF(w, PHYS_STAGE_ROWS); hipLaunchKernelGGL(k_color_place, dim3(nb), dim3(1024), 0, s, w->max_manifolds, w->man_color.p, w->color_block_hist.p, nb, w->row_src.p, w->counters.p); }
     snapshot_counters_async(w);
 }
 
