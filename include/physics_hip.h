@@ -184,10 +184,11 @@ typedef struct phys_device_view {
     uint64_t n;
     float* pos;     /* 3n */
     float* rot;     /* 4n */
-    float* lin_vel; /* 3n */
-    float* ang_vel; /* 3n */
+    float* lin_vel; /* 3 floats per body at a stride of vel_stride floats */
+    float* ang_vel; /* 3 floats per body at a stride of vel_stride floats */
     float* aabb;    /* 6n: min xyz max xyz, valid after an update with COLLISIONS or phys_broadphase */
     void* stream;   /* hipStream_t the world launches on */
+    uint64_t vel_stride; /* = 8: velocities live in 32-byte records {v.xyz, 1/m, w.xyz, m} */
 } phys_device_view;
 int32_t phys_get_device_view(phys_world* w, phys_device_view* out);
 

@@ -84,6 +84,7 @@ class PhysDeviceView(C.Structure):
         ("ang_vel", C.c_void_p),
         ("aabb", C.c_void_p),
         ("stream", C.c_void_p),
+        ("vel_stride", C.c_uint64),
     ]
 
 

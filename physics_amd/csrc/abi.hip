@@ -130,7 +130,7 @@ int32_t phys_destroy(phys_world* w) {
     if (!w) return PHYS_OK;
     (void)hipSetDevice(w->device);
     if (w->stream) (void)hipStreamSynchronize(w->stream);
-    DevBuf<float>* fb[] = {&w->pos, &w->rot, &w->lin, &w->ang, &w->force, &w->torque, &w->mass, &w->inv_mass,
+    DevBuf<float>* fb[] = {&w->pos, &w->rot, &w->vel, &w->force, &w->torque,
                            &w->inv_inertia, &w->half_extent, &w->aabb, &w->cg_x, &w->cg_r, &w->cg_p, &w->cg_ap,
                            &w->cg_rhs, &w->cg_c, &w->cg_scratch, &w->man_normal, &w->man_points, &w->row_normal,
                            &w->row_data, &w->row_acc, &w->sorted_box};
@@ -160,9 +160,9 @@ int32_t phys_set_bodies(phys_world* w, uint64_t n, const float* pos, const float
     if (n && !pos) return fail(PHYS_ERR_INVALID_ARG, "pos is required");
     if (n >= 0x7FFFFFFFull) return fail(PHYS_ERR_INVALID_ARG, "too many bodies (u32 indices)");
     PHYS_HIP_TRY(hipStreamSynchronize(w->stream));
-    PHYS_HIP_TRY(w->pos.resize(3 * n)); PHYS_HIP_TRY(w->rot.resize(4 * n)); PHYS_HIP_TRY(w->lin.resize(3 * n));
-    PHYS_HIP_TRY(w->ang.resize(3 * n)); PHYS_HIP_TRY(w->force.resize(3 * n)); PHYS_HIP_TRY(w->torque.resize(3 * n));
-    PHYS_HIP_TRY(w->mass.resize(n)); PHYS_HIP_TRY(w->inv_mass.resize(n)); PHYS_HIP_TRY(w->inv_inertia.resize(9 * n));
+    PHYS_HIP_TRY(w->pos.resize(3 * n)); PHYS_HIP_TRY(w->rot.resize(4 * n)); PHYS_HIP_TRY(w->vel.resize(8 * n));
+    PHYS_HIP_TRY(w->force.resize(3 * n)); PHYS_HIP_TRY(w->torque.resize(3 * n));
+    PHYS_HIP_TRY(w->inv_inertia.resize(9 * n));
     PHYS_HIP_TRY(w->half_extent.resize(3 * n)); PHYS_HIP_TRY(w->aabb.resize(6 * n)); PHYS_HIP_TRY(w->shape.resize(n));
     PHYS_HIP_TRY(w->global_id.resize(n));
     w->n = n;
@@ -175,15 +175,17 @@ int32_t phys_set_bodies(phys_world* w, uint64_t n, const float* pos, const float
     if (n == 0) return PHYS_OK;
 
     // host staging with RigidBody::new defaults (rigid_body.rs:64-76)
-    std::vector<float> h_rot(4 * n), h_mass(n), h_invm(n), h_inv(9 * n), h_zero3(3 * n, 0.0f), h_he(3 * n, 0.0f);
+    std::vector<float> h_rot(4 * n), h_vel(8 * n), h_inv(9 * n), h_he(3 * n, 0.0f);
     std::vector<uint32_t> h_shape(n, PHYS_SHAPE_NONE), h_gid(n);
     w->singular_inertia = false;
     w->all_diag_inertia = true;
     for (uint64_t i = 0; i < n; ++i) {
         if (rot) std::memcpy(&h_rot[4 * i], rot + 4 * i, 16);
         else { h_rot[4 * i] = 0.0f; h_rot[4 * i + 1] = 0.0f; h_rot[4 * i + 2] = 0.0f; h_rot[4 * i + 3] = 1.0f; }
-        h_mass[i] = mass ? mass[i] : 1.0f;
-        h_invm[i] = 1.0f / h_mass[i];  // constraints.rs:75
+        const float m_i = mass ? mass[i] : 1.0f;
+        for (int k = 0; k < 3; ++k) { h_vel[8 * i + k] = lin ? lin[3 * i + k] : 0.0f; h_vel[8 * i + 4 + k] = ang ? ang[3 * i + k] : 0.0f; }
+        h_vel[8 * i + 3] = 1.0f / m_i;  // constraints.rs:75
+        h_vel[8 * i + 7] = m_i;
         m33 I, inv;
         for (int k = 0; k < 9; ++k) I.m[k] = inertia ? inertia[9 * i + k] : ((k % 4 == 0) ? 1.0f : 0.0f);
         // The reference inverts the (constant, world-frame) tensor every step (rigid_body.rs:31, quirk Q5);
@@ -203,12 +205,9 @@ int32_t phys_set_bodies(phys_world* w, uint64_t n, const float* pos, const float
     hipStream_t s = w->stream;
     PHYS_HIP_TRY(hipMemcpyAsync(w->pos.p, pos, 12 * n, hipMemcpyHostToDevice, s));
     PHYS_HIP_TRY(hipMemcpyAsync(w->rot.p, h_rot.data(), 16 * n, hipMemcpyHostToDevice, s));
-    PHYS_HIP_TRY(hipMemcpyAsync(w->lin.p, lin ? lin : h_zero3.data(), 12 * n, hipMemcpyHostToDevice, s));
-    PHYS_HIP_TRY(hipMemcpyAsync(w->ang.p, ang ? ang : h_zero3.data(), 12 * n, hipMemcpyHostToDevice, s));
+    PHYS_HIP_TRY(hipMemcpyAsync(w->vel.p, h_vel.data(), 32 * n, hipMemcpyHostToDevice, s));
     PHYS_HIP_TRY(hipMemsetAsync(w->force.p, 0, 12 * n, s));
     PHYS_HIP_TRY(hipMemsetAsync(w->torque.p, 0, 12 * n, s));
-    PHYS_HIP_TRY(hipMemcpyAsync(w->mass.p, h_mass.data(), 4 * n, hipMemcpyHostToDevice, s));
-    PHYS_HIP_TRY(hipMemcpyAsync(w->inv_mass.p, h_invm.data(), 4 * n, hipMemcpyHostToDevice, s));
     PHYS_HIP_TRY(hipMemcpyAsync(w->inv_inertia.p, h_inv.data(), 36 * n, hipMemcpyHostToDevice, s));
     PHYS_HIP_TRY(hipMemcpyAsync(w->half_extent.p, h_he.data(), 12 * n, hipMemcpyHostToDevice, s));
     PHYS_HIP_TRY(hipMemcpyAsync(w->shape.p, h_shape.data(), 4 * n, hipMemcpyHostToDevice, s));
@@ -306,7 +305,11 @@ static int32_t enqueue_update(phys_world* w, float dt) {
     if (!collisions) {
         launch_step_full(w, dt, gravity_pending);
     } else {
-        { PHYS_PROF(w, PHYS_STAGE_MISC); PHYS_HIP_TRY(hipMemsetAsync(w->counters.p, 0, sizeof(StepCounters), w->stream)); }
+        {
+            PHYS_PROF(w, PHYS_STAGE_MISC);
+            const size_t bytes = (w->steps % 32 == 0) ? sizeof(StepCounters) : kCountersStepResetBytes;
+            PHYS_HIP_TRY(hipMemsetAsync(w->counters.p, 0, bytes, w->stream));
+        }
         launch_step_velocity_aabb(w, dt, gravity_pending);
         launch_broadphase(w);
         if (!(w->cfg.flags & PHYS_FLAG_BROADPHASE_ONLY)) {
@@ -366,8 +369,9 @@ int32_t phys_get_transforms(phys_world* w, float* pos_out, float* rot_out) {
 }
 int32_t phys_get_velocities(phys_world* w, float* lin_out, float* ang_out) {
     ENTER(w);
-    int32_t rc = d2h(w, lin_out, w->lin.p, 12 * w->n); if (rc) return rc;
-    rc = d2h(w, ang_out, w->ang.p, 12 * w->n); if (rc) return rc;
+    // strided read-out of the 32-byte velocity records: 12 bytes per body from a 32-byte pitch
+    if (lin_out && w->n) PHYS_HIP_TRY(hipMemcpy2DAsync(lin_out, 12, w->vel.p, 32, 12, w->n, hipMemcpyDeviceToHost, w->stream));
+    if (ang_out && w->n) PHYS_HIP_TRY(hipMemcpy2DAsync(ang_out, 12, w->vel.p + 4, 32, 12, w->n, hipMemcpyDeviceToHost, w->stream));
     PHYS_HIP_TRY(hipStreamSynchronize(w->stream));
     return PHYS_OK;
 }
@@ -507,9 +511,10 @@ int32_t phys_get_device_view(phys_world* w, phys_device_view* out) {
     ENTER(w);
     if (!out) return fail(PHYS_ERR_INVALID_ARG, "null output");
     out->n = w->n;
-    out->pos = w->pos.p; out->rot = w->rot.p; out->lin_vel = w->lin.p; out->ang_vel = w->ang.p;
+    out->pos = w->pos.p; out->rot = w->rot.p; out->lin_vel = w->vel.p; out->ang_vel = w->vel.p + 4;  // both with a stride of 8 floats
     out->aabb = w->aabb.p;
     out->stream = (void*)w->stream;
+    out->vel_stride = 8;
     return PHYS_OK;
 }
 

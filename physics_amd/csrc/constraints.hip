@@ -108,8 +108,7 @@ __global__ __launch_bounds__(kCgThreads) void k_constraint_solve(
     CgParams cp, const Constraint* __restrict__ cons, const uint32_t* __restrict__ col_ptr,
     const uint32_t* __restrict__ col_rows, const uint32_t* __restrict__ col_id, const uint32_t* __restrict__ row_cidx,
     float* __restrict__ col_w, const float* __restrict__ pos, const float* __restrict__ rot,
-    const float* __restrict__ lin, const float* __restrict__ ang, float* __restrict__ force, float* __restrict__ torque,
-    const float* __restrict__ inv_mass, float* __restrict__ x_prev, float* __restrict__ x, float* __restrict__ r,
+    const float* __restrict__ vel, float* __restrict__ force, float* __restrict__ torque, float* __restrict__ x_prev, float* __restrict__ x, float* __restrict__ r,
     float* __restrict__ p, float* __restrict__ ap, float* __restrict__ rhs, float* __restrict__ tcol,
     uint32_t* __restrict__ status /* [0] converged, [1] iterations, [2] previous_solution.is_some() */) {
     __shared__ float lds8[8];
@@ -118,7 +117,7 @@ __global__ __launch_bounds__(kCgThreads) void k_constraint_solve(
     const uint32_t n = 3 * cp.n_constraints;
 
     // constraint-space inverse masses of the selected columns: 1/mass for all six (quirk Q4, constraints.rs:72-78)
-    for (uint32_t u = threadIdx.x; u < cp.n_cols; u += kCgThreads) col_w[u] = inv_mass[col_id[u] / 6];
+    for (uint32_t u = threadIdx.x; u < cp.n_cols; u += kCgThreads) col_w[u] = vel[8 * (size_t)(col_id[u] / 6) + 3];
     // rhs = -Jdot*qdot - J(Q o W) - ks o C - kd o (J qdot)   (constraints.rs:153-160), Jdot = 0
     for (uint32_t c = threadIdx.x; c < cp.n_constraints; c += kCgThreads) {
         const Constraint con = cons[c];
@@ -127,7 +126,7 @@ __global__ __launch_bounds__(kCgThreads) void k_constraint_solve(
         if (con.kind == 0u) {
             const v3 x0 = ld3(pos, b);
             cv[0] = x0.x - con.target[0]; cv[1] = x0.y - con.target[1]; cv[2] = x0.z - con.target[2];
-            const v3 v = ld3(lin, b), F = ld3(force, b);
+            const v3 v = ld_vel(vel, b).v, F = ld3(force, b);
             qd[0] = v.x; qd[1] = v.y; qd[2] = v.z;
             Q[0] = F.x; Q[1] = F.y; Q[2] = F.z;
         } else {
@@ -136,11 +135,11 @@ __global__ __launch_bounds__(kCgThreads) void k_constraint_solve(
             float rpy[3];
             quat_euler_angles(q, rpy);
             cv[0] = rpy[0] - con.target[0]; cv[1] = rpy[1] - con.target[1]; cv[2] = rpy[2] - con.target[2];
-            const v3 wv = ld3(ang, b), T = ld3(torque, b);
+            const v3 wv = ld_vel(vel, b).w, T = ld3(torque, b);
             qd[0] = wv.x; qd[1] = wv.y; qd[2] = wv.z;
             Q[0] = T.x; Q[1] = T.y; Q[2] = T.z;
         }
-        const float W = inv_mass[b];
+        const float W = vel[8 * (size_t)b + 3];
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             const float kd = 1.0f * qd[k];   // k_d o c_dot, KD = 1
@@ -250,8 +249,8 @@ void launch_constraint_phase(phys_world* w) {
     uint32_t* base = w->cg_cols.p;
     PHYS_PROF(w, PHYS_STAGE_CONSTRAINTS);
     hipLaunchKernelGGL(k_constraint_solve, dim3(1), dim3(kCgThreads), 0, w->stream, cp, w->d_constraints.p, base + U,
-                       base + 2 * U + 1, base, base + 2 * U + 1 + n, w->cg_scratch.p + U, w->pos.p, w->rot.p, w->lin.p,
-                       w->ang.p, w->force.p, w->torque.p, w->inv_mass.p, w->cg_x.p, w->cg_x.p + n, w->cg_r.p, w->cg_p.p,
+                       base + 2 * U + 1, base, base + 2 * U + 1 + n, w->cg_scratch.p + U, w->pos.p, w->rot.p, w->vel.p,
+                       w->force.p, w->torque.p, w->cg_x.p, w->cg_x.p + n, w->cg_r.p, w->cg_p.p,
                        w->cg_ap.p, w->cg_rhs.p, w->cg_scratch.p, w->cg_status.p);
 }
 

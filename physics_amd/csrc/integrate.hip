@@ -74,10 +74,8 @@ __device__ __forceinline__ void integrate_position(float dt, v3 v, v3 w, v3& x, 
 // GRAVITY: fold apply_gravity in (update path); off for a bare phys_step.
 template <bool FORCES, bool GRAVITY, bool DIAG, bool EXACT_ROT>
 __global__ __launch_bounds__(256) void k_step_full(StepParams sp, float* __restrict__ pos, float* __restrict__ rot,
-                                                   float* __restrict__ lin, float* __restrict__ ang,
-                                                   float* __restrict__ force, float* __restrict__ torque,
-                                                   const float* __restrict__ mass,
-                                                   const float* __restrict__ inv_inertia) {
+                                                   float* __restrict__ vel, float* __restrict__ force,
+                                                   float* __restrict__ torque, const float* __restrict__ inv_inertia) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= sp.n) return;
     v3 F = v3_make(0.0f, 0.0f, 0.0f), T = v3_make(0.0f, 0.0f, 0.0f);
@@ -87,12 +85,13 @@ __global__ __launch_bounds__(256) void k_step_full(StepParams sp, float* __restr
         T = v3_add(T, v3_make(sp.g_torque[0], sp.g_torque[1], sp.g_torque[2]));
         F = v3_add(F, v3_make(sp.g_force[0], sp.g_force[1], sp.g_force[2]));
     }
-    v3 v = ld3(lin, i), w = ld3(ang, i), x = ld3(pos, i);
+    BodyVel bv = ld_vel(vel, i);
+    v3 x = ld3(pos, i);
     float4 qq = reinterpret_cast<float4*>(rot)[i];
     quat q; q.i = qq.x; q.j = qq.y; q.k = qq.z; q.w = qq.w;
-    integrate_velocity<DIAG>(F, T, mass[i], inv_inertia, i, sp.dt, v, w);
-    integrate_position<EXACT_ROT>(sp.dt, v, w, x, q);
-    st3(lin, i, v); st3(ang, i, w); st3(pos, i, x);
+    integrate_velocity<DIAG>(F, T, bv.mass, inv_inertia, i, sp.dt, bv.v, bv.w);
+    integrate_position<EXACT_ROT>(sp.dt, bv.v, bv.w, x, q);
+    st_vel(vel, i, bv); st3(pos, i, x);
     reinterpret_cast<float4*>(rot)[i] = make_float4(q.i, q.j, q.k, q.w);
     if (FORCES) { st3(force, i, v3_make(0.0f, 0.0f, 0.0f)); st3(torque, i, v3_make(0.0f, 0.0f, 0.0f)); }
 }
@@ -100,9 +99,8 @@ __global__ __launch_bounds__(256) void k_step_full(StepParams sp, float* __restr
 // collision mode, first half: [gravity] + velocity update + fattened AABB + largest-extent reduction
 template <bool FORCES, bool GRAVITY, bool DIAG>
 __global__ __launch_bounds__(256) void k_step_velocity_aabb(StepParams sp, const float* __restrict__ pos,
-                                                            const float* __restrict__ rot, float* __restrict__ lin,
-                                                            float* __restrict__ ang, float* __restrict__ force,
-                                                            float* __restrict__ torque, const float* __restrict__ mass,
+                                                            const float* __restrict__ rot, float* __restrict__ vel,
+                                                            float* __restrict__ force, float* __restrict__ torque,
                                                             const float* __restrict__ inv_inertia,
                                                             const uint32_t* __restrict__ shape,
                                                             const float* __restrict__ half_extent, float margin,
@@ -116,9 +114,9 @@ __global__ __launch_bounds__(256) void k_step_velocity_aabb(StepParams sp, const
             T = v3_add(T, v3_make(sp.g_torque[0], sp.g_torque[1], sp.g_torque[2]));
             F = v3_add(F, v3_make(sp.g_force[0], sp.g_force[1], sp.g_force[2]));
         }
-        v3 v = ld3(lin, i), w = ld3(ang, i);
-        integrate_velocity<DIAG>(F, T, mass[i], inv_inertia, i, sp.dt, v, w);
-        st3(lin, i, v); st3(ang, i, w);
+        BodyVel bv = ld_vel(vel, i);
+        integrate_velocity<DIAG>(F, T, bv.mass, inv_inertia, i, sp.dt, bv.v, bv.w);
+        st_vel(vel, i, bv);
         if (FORCES) { st3(force, i, v3_make(0.0f, 0.0f, 0.0f)); st3(torque, i, v3_make(0.0f, 0.0f, 0.0f)); }
         const v3 x = ld3(pos, i);
         const float4 qq = reinterpret_cast<const float4*>(rot)[i];
@@ -174,12 +172,12 @@ __global__ __launch_bounds__(256) void k_aabb_only(uint32_t n, const float* __re
 // collision mode, second half: position + rotation update
 template <bool EXACT_ROT>
 __global__ __launch_bounds__(256) void k_step_position(uint32_t n, float dt, float* __restrict__ pos,
-                                                       float* __restrict__ rot, const float* __restrict__ lin,
-                                                       const float* __restrict__ ang) {
+                                                       float* __restrict__ rot, const float* __restrict__ vel) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     v3 x = ld3(pos, i);
-    const v3 v = ld3(lin, i), w = ld3(ang, i);
+    const BodyVel bv = ld_vel(vel, i);
+    const v3 v = bv.v, w = bv.w;
     float4 qq = reinterpret_cast<float4*>(rot)[i];
     quat q; q.i = qq.x; q.j = qq.y; q.k = qq.z; q.w = qq.w;
     integrate_position<EXACT_ROT>(dt, v, w, x, q);
@@ -248,8 +246,8 @@ static void launch_full(phys_world* w, const StepParams& sp) {
     const bool exact = (w->cfg.flags & PHYS_FLAG_EXACT_ROTATION) != 0;
     const dim3 g = grid_for(w->n), b(256);
 #define LAUNCH(D, E)                                                                                              \
-    hipLaunchKernelGGL((k_step_full<FORCES, GRAVITY, D, E>), g, b, 0, w->stream, sp, w->pos.p, w->rot.p, w->lin.p, \
-                       w->ang.p, w->force.p, w->torque.p, w->mass.p, w->inv_inertia.p)
+    hipLaunchKernelGGL((k_step_full<FORCES, GRAVITY, D, E>), g, b, 0, w->stream, sp, w->pos.p, w->rot.p, w->vel.p, \
+                       w->force.p, w->torque.p, w->inv_inertia.p)
     PHYS_PROF(w, PHYS_STAGE_STEP_FULL);
     if (diag && exact) LAUNCH(true, true);
     else if (diag) LAUNCH(true, false);
@@ -274,8 +272,8 @@ void launch_step_velocity_aabb(phys_world* w, float dt, bool gravity) {
     const bool diag = w->all_diag_inertia;
     const float margin = w->cfg.contact_margin;
 #define LAUNCH(F, G, D)                                                                                            \
-    hipLaunchKernelGGL((k_step_velocity_aabb<F, G, D>), g, b, 0, w->stream, sp, w->pos.p, w->rot.p, w->lin.p,      \
-                       w->ang.p, w->force.p, w->torque.p, w->mass.p, w->inv_inertia.p, w->shape.p,                \
+    hipLaunchKernelGGL((k_step_velocity_aabb<F, G, D>), g, b, 0, w->stream, sp, w->pos.p, w->rot.p, w->vel.p,      \
+                       w->force.p, w->torque.p, w->inv_inertia.p, w->shape.p,                \
                        w->half_extent.p, margin, w->aabb.p, w->counters.p)
     const int sel = (w->forces_dirty ? 4 : 0) | (gravity ? 2 : 0) | (diag ? 1 : 0);
     PHYS_PROF(w, PHYS_STAGE_VELOCITY_AABB);
@@ -307,9 +305,9 @@ void launch_step_position(phys_world* w, float dt) {
     const dim3 g = grid_for(w->n), b(256);
     PHYS_PROF(w, PHYS_STAGE_POSITION);
     if (w->cfg.flags & PHYS_FLAG_EXACT_ROTATION)
-        hipLaunchKernelGGL((k_step_position<true>), g, b, 0, w->stream, (uint32_t)w->n, dt, w->pos.p, w->rot.p, w->lin.p, w->ang.p);
+        hipLaunchKernelGGL((k_step_position<true>), g, b, 0, w->stream, (uint32_t)w->n, dt, w->pos.p, w->rot.p, w->vel.p);
     else
-        hipLaunchKernelGGL((k_step_position<false>), g, b, 0, w->stream, (uint32_t)w->n, dt, w->pos.p, w->rot.p, w->lin.p, w->ang.p);
+        hipLaunchKernelGGL((k_step_position<false>), g, b, 0, w->stream, (uint32_t)w->n, dt, w->pos.p, w->rot.p, w->vel.p);
     w->aabbs_valid = false;
 }
 

@@ -30,6 +30,24 @@ __device__ __forceinline__ void st3(float* __restrict__ p, uint32_t i, v3 v) {
     reinterpret_cast<packed3*>(p)[i] = t;
 }
 
+// Velocity record of one body: 32 bytes {v.xyz, inv_mass, w.xyz, mass} = two dwordx4 accesses and ONE
+// 32-byte sector per gather (the solver gathers it by body id 8 x colours times per step), instead of pieces
+// of three separate arrays. lin_velocity / angular_velocity of the reference (rigid_body.rs:9-10) are the
+// first three floats of each half.
+struct BodyVel { v3 v; float inv_mass; v3 w; float mass; };
+__device__ __forceinline__ BodyVel ld_vel(const float* __restrict__ vel, uint32_t i) {
+    const float4 a = reinterpret_cast<const float4*>(vel)[2 * (size_t)i];
+    const float4 b = reinterpret_cast<const float4*>(vel)[2 * (size_t)i + 1];
+    BodyVel r;
+    r.v = v3_make(a.x, a.y, a.z); r.inv_mass = a.w;
+    r.w = v3_make(b.x, b.y, b.z); r.mass = b.w;
+    return r;
+}
+__device__ __forceinline__ void st_vel(float* __restrict__ vel, uint32_t i, const BodyVel& r) {
+    reinterpret_cast<float4*>(vel)[2 * (size_t)i] = make_float4(r.v.x, r.v.y, r.v.z, r.inv_mass);
+    reinterpret_cast<float4*>(vel)[2 * (size_t)i + 1] = make_float4(r.w.x, r.w.y, r.w.z, r.mass);
+}
+
 // integrate.hip
 void launch_step_full(phys_world* w, float dt, bool gravity);
 void launch_step_velocity_aabb(phys_world* w, float dt, bool gravity);

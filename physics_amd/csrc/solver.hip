@@ -36,7 +36,7 @@ __global__ __launch_bounds__(256) void k_rows_build(const StepCounters* __restri
                                                     const uint32_t* __restrict__ man_count,
                                                     const float* __restrict__ man_normal,
                                                     const float* __restrict__ man_points, const float* __restrict__ pos,
-                                                    const float* __restrict__ inv_mass,
+                                                    const float* __restrict__ vel,
                                                     const float* __restrict__ inv_inertia, uint32_t* __restrict__ row_a,
                                                     uint32_t* __restrict__ row_b, uint32_t* __restrict__ row_count,
                                                     float* __restrict__ row_normal, float* __restrict__ row_data,
@@ -63,9 +63,9 @@ __global__ __launch_bounds__(256) void k_rows_build(const StepCounters* __restri
     for (int k = 0; k < 9; ++k) IB.m[k] = 0.0f;
     float imb = 0.0f;
     v3 xB = v3_make(0.0f, 0.0f, 0.0f);
-    if (has_b) { IB = ld_m33(inv_inertia, b); imb = inv_mass[b]; xB = ld3(pos, b); }
+    if (has_b) { IB = ld_m33(inv_inertia, b); imb = vel[8 * (size_t)b + 3]; xB = ld3(pos, b); }
     solver_manifold_t sm;
-    solver_prep(&g, has_b, ld3(pos, a), xB, inv_mass[a], &IA, imb, &IB, &sp, &sm);
+    solver_prep(&g, has_b, ld3(pos, a), xB, vel[8 * (size_t)a + 3], &IA, imb, &IB, &sp, &sm);
     row_a[d] = a; row_b[d] = b; row_count[d] = (uint32_t)sm.count;
     row_normal[0 * cap + d] = sm.n.x; row_normal[1 * cap + d] = sm.n.y; row_normal[2 * cap + d] = sm.n.z;
 #pragma unroll
@@ -88,9 +88,8 @@ __global__ __launch_bounds__(256) void k_rows_build(const StepCounters* __restri
 __device__ __forceinline__ void solve_row(uint32_t d, uint64_t cap, float friction, const uint32_t* __restrict__ row_a,
                                           const uint32_t* __restrict__ row_b, const uint32_t* __restrict__ row_count,
                                           const float* __restrict__ row_normal, const float* __restrict__ row_data,
-                                          float* __restrict__ row_acc, const float* __restrict__ inv_mass,
-                                          const float* __restrict__ inv_inertia, float* __restrict__ lin,
-                                          float* __restrict__ ang) {
+                                          float* __restrict__ row_acc, const float* __restrict__ inv_inertia,
+                                          float* __restrict__ vel) {
     const uint32_t a = row_a[d], b = row_b[d];
     solver_manifold_t sm;
     sm.count = (int)row_count[d];
@@ -115,17 +114,20 @@ __device__ __forceinline__ void solve_row(uint32_t d, uint64_t cap, float fricti
         }
     }
     const m33 IA = ld_m33(inv_inertia, a);
-    const float ima = inv_mass[a];
-    v3 vA = ld3(lin, a), wA = ld3(ang, a);
+    BodyVel A = ld_vel(vel, a);
+    const float ima = A.inv_mass;
+    v3 vA = A.v, wA = A.w;
     m33 IB;
 #pragma unroll
     for (int k = 0; k < 9; ++k) IB.m[k] = 0.0f;
     float imb = 0.0f;
     v3 vB = v3_make(0.0f, 0.0f, 0.0f), wB = v3_make(0.0f, 0.0f, 0.0f);
-    if (sm.has_b) { IB = ld_m33(inv_inertia, b); imb = inv_mass[b]; vB = ld3(lin, b); wB = ld3(ang, b); }
+    BodyVel B = A;
+    if (sm.has_b) { IB = ld_m33(inv_inertia, b); B = ld_vel(vel, b); imb = B.inv_mass; vB = B.v; wB = B.w; }
     solve_manifold(&sm, friction, ima, &IA, imb, &IB, &vA, &wA, &vB, &wB);
-    st3(lin, a, vA); st3(ang, a, wA);
-    if (sm.has_b) { st3(lin, b, vB); st3(ang, b, wB); }
+    A.v = vA; A.w = wA;
+    st_vel(vel, a, A);
+    if (sm.has_b) { B.v = vB; B.w = wB; st_vel(vel, b, B); }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         if (k < sm.count) {
@@ -142,13 +144,11 @@ __global__ __launch_bounds__(256) void k_solve_color(const StepCounters* __restr
                                                      const uint32_t* __restrict__ row_count,
                                                      const float* __restrict__ row_normal,
                                                      const float* __restrict__ row_data, float* __restrict__ row_acc,
-                                                     const float* __restrict__ inv_mass,
-                                                     const float* __restrict__ inv_inertia, float* __restrict__ lin,
-                                                     float* __restrict__ ang) {
+                                                     const float* __restrict__ inv_inertia, float* __restrict__ vel) {
     if (ctr->overflow) return;
     const uint32_t start = ctr->color_start[col], end = ctr->color_start[col + 1];
     for (uint32_t d = start + blockIdx.x * blockDim.x + threadIdx.x; d < end; d += gridDim.x * blockDim.x)
-        solve_row(d, cap, friction, row_a, row_b, row_count, row_normal, row_data, row_acc, inv_mass, inv_inertia, lin, ang);
+        solve_row(d, cap, friction, row_a, row_b, row_count, row_normal, row_data, row_acc, inv_inertia, vel);
 }
 
 // The colour classes [first, n_colours) of one iteration in ONE launch of ONE workgroup: colours in
@@ -163,15 +163,13 @@ __global__ __launch_bounds__(kTailThreads) void k_solve_tail(const StepCounters*
                                                             const uint32_t* __restrict__ row_count,
                                                             const float* __restrict__ row_normal,
                                                             const float* __restrict__ row_data, float* __restrict__ row_acc,
-                                                            const float* __restrict__ inv_mass,
-                                                            const float* __restrict__ inv_inertia, float* __restrict__ lin,
-                                                            float* __restrict__ ang) {
+                                                            const float* __restrict__ inv_inertia, float* __restrict__ vel) {
     if (ctr->overflow) return;
     const uint32_t last = ctr->n_colors;
     for (uint32_t col = first; col < last; ++col) {
         const uint32_t start = ctr->color_start[col], end = ctr->color_start[col + 1];
         for (uint32_t d = start + threadIdx.x; d < end; d += kTailThreads)
-            solve_row(d, cap, friction, row_a, row_b, row_count, row_normal, row_data, row_acc, inv_mass, inv_inertia, lin, ang);
+            solve_row(d, cap, friction, row_a, row_b, row_count, row_normal, row_data, row_acc, inv_inertia, vel);
         __threadfence_block();
         __syncthreads();
     }
@@ -200,7 +198,7 @@ void launch_solver(phys_world* w, float dt) {
     };
     const uint64_t m_hint = h.valid ? h.n_manifolds : cap;
     { PHYS_PROF(w, PHYS_STAGE_ROWS); hipLaunchKernelGGL(k_rows_build, grid_for_count(m_hint), tb, 0, s, w->counters.p, cap, sp, w->row_src.p, w->man_a.p, w->man_b.p, w->man_count.p,
-                       w->man_normal.p, w->man_points.p, w->pos.p, w->inv_mass.p, w->inv_inertia.p, w->row_a.p,
+                       w->man_normal.p, w->man_points.p, w->pos.p, w->vel.p, w->inv_inertia.p, w->row_a.p,
                        w->row_b.p, w->row_count.p, w->row_normal.p, w->row_data.p, w->row_acc.p); }
     // colours [0, big) get a launch each; [big, n_colours) go through the single-workgroup tail
     constexpr uint32_t kTailMax = 512;  // manifolds per colour the tail should take: one trip of the workgroup
@@ -215,12 +213,12 @@ void launch_solver(phys_world* w, float dt) {
             PHYS_PROF(w, PHYS_STAGE_SOLVE);
             hipLaunchKernelGGL(k_solve_color, grid_for_count(h.color_count[col]), tb, 0, s, w->counters.p, col, cap, sp.friction,
                                w->row_a.p, w->row_b.p, w->row_count.p, w->row_normal.p, w->row_data.p, w->row_acc.p,
-                               w->inv_mass.p, w->inv_inertia.p, w->lin.p, w->ang.p);
+                               w->inv_inertia.p, w->vel.p);
         }
         PHYS_PROF(w, PHYS_STAGE_SOLVE);
         hipLaunchKernelGGL(k_solve_tail, dim3(1), dim3(kTailThreads), 0, s, w->counters.p, big, cap, sp.friction,
                            w->row_a.p, w->row_b.p, w->row_count.p, w->row_normal.p, w->row_data.p, w->row_acc.p,
-                           w->inv_mass.p, w->inv_inertia.p, w->lin.p, w->ang.p);
+                           w->inv_inertia.p, w->vel.p);
     }
 }
 

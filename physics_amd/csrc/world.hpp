@@ -6,6 +6,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <cstddef>
 #include <cstdint>
 #include <string>
 #include <vector>
@@ -58,14 +59,19 @@ struct StepCounters {
     uint32_t n_colors;       // colours in use
     uint32_t color_rounds;
     uint32_t overflow;       // bit 0 pairs, bit 1 manifolds, bit 2 colours, bit 3 cross pairs
-    uint32_t max_extent_bits;  // float bits of the largest AABB extent (positive floats order as uints)
     uint32_t n_halo;         // halo records packed
     uint32_t n_cross_pairs;
     uint32_t n_ground_manifolds;
     uint32_t color_count[kMaxColors];  // manifolds per colour
     uint32_t color_start[kMaxColors + 1];
     uint32_t color_cursor[kMaxColors];
+    // LAST member: survives the per-step reset (only the bytes before it are zeroed), so a wave issues the
+    // same-address atomicMax only when it RAISES the bound. It is a running upper bound of the largest
+    // fattened-AABB edge (float bits; positive floats order as uints), re-derived from zero every 32 steps.
+    // Any upper bound is a valid grid cell size: the pair SET does not depend on it.
+    uint32_t max_extent_bits;
 };
+constexpr size_t kCountersStepResetBytes = offsetof(StepCounters, max_extent_bits);
 
 // per-stage device timing with HIP events on the world's stream (phys_profile_enable)
 struct Profiler {
@@ -134,7 +140,7 @@ struct phys_world {
     bool grid_valid = false;  // bucket grid + AABBs of the last broad phase are on the device (halo entry points)
 
     // body SoA
-    phys::DevBuf<float> pos, rot, lin, ang, force, torque, mass, inv_mass, inv_inertia, half_extent, aabb;
+    phys::DevBuf<float> pos, rot, vel /* 8n: v.xyz inv_mass w.xyz mass */, force, torque, inv_inertia, half_extent, aabb;
     phys::DevBuf<uint32_t> shape;
     phys::DevBuf<uint32_t> global_id;
 
