@@ -130,7 +130,7 @@ int32_t phys_destroy(phys_world* w) {
     if (!w) return PHYS_OK;
     (void)hipSetDevice(w->device);
     if (w->stream) (void)hipStreamSynchronize(w->stream);
-    DevBuf<float>* fb[] = {&w->pos, &w->rot, &w->vel, &w->force, &w->torque,
+    DevBuf<float>* fb[] = {&w->pos, &w->rot, &w->vel, &w->force, &w->torque, &w->inv_inertia_diag,
                            &w->inv_inertia, &w->half_extent, &w->aabb, &w->cg_x, &w->cg_r, &w->cg_p, &w->cg_ap,
                            &w->cg_rhs, &w->cg_c, &w->cg_scratch, &w->man_normal, &w->man_points, &w->row_normal,
                            &w->row_data, &w->row_acc, &w->sorted_box};
@@ -162,7 +162,7 @@ int32_t phys_set_bodies(phys_world* w, uint64_t n, const float* pos, const float
     PHYS_HIP_TRY(hipStreamSynchronize(w->stream));
     PHYS_HIP_TRY(w->pos.resize(3 * n)); PHYS_HIP_TRY(w->rot.resize(4 * n)); PHYS_HIP_TRY(w->vel.resize(8 * n));
     PHYS_HIP_TRY(w->force.resize(3 * n)); PHYS_HIP_TRY(w->torque.resize(3 * n));
-    PHYS_HIP_TRY(w->inv_inertia.resize(9 * n));
+    PHYS_HIP_TRY(w->inv_inertia.resize(9 * n)); PHYS_HIP_TRY(w->inv_inertia_diag.resize(4 * n));
     PHYS_HIP_TRY(w->half_extent.resize(3 * n)); PHYS_HIP_TRY(w->aabb.resize(6 * n)); PHYS_HIP_TRY(w->shape.resize(n));
     PHYS_HIP_TRY(w->global_id.resize(n));
     w->n = n;
@@ -175,7 +175,7 @@ int32_t phys_set_bodies(phys_world* w, uint64_t n, const float* pos, const float
     if (n == 0) return PHYS_OK;
 
     // host staging with RigidBody::new defaults (rigid_body.rs:64-76)
-    std::vector<float> h_rot(4 * n), h_vel(8 * n), h_inv(9 * n), h_he(3 * n, 0.0f);
+    std::vector<float> h_rot(4 * n), h_vel(8 * n), h_inv(9 * n), h_diag(4 * n, 0.0f), h_he(3 * n, 0.0f);
     std::vector<uint32_t> h_shape(n, PHYS_SHAPE_NONE), h_gid(n);
     w->singular_inertia = false;
     w->all_diag_inertia = true;
@@ -198,6 +198,7 @@ int32_t phys_set_bodies(phys_world* w, uint64_t n, const float* pos, const float
             h_inv[9 * i + k] = inv.m[k];
             if (k % 4 != 0 && inv.m[k] != 0.0f) w->all_diag_inertia = false;
         }
+        h_diag[4 * i] = inv.m[0]; h_diag[4 * i + 1] = inv.m[4]; h_diag[4 * i + 2] = inv.m[8];
         if (shape_type) h_shape[i] = shape_type[i];
         if (half_extent) std::memcpy(&h_he[3 * i], half_extent + 3 * i, 12);
         h_gid[i] = (uint32_t)i;
@@ -209,6 +210,7 @@ int32_t phys_set_bodies(phys_world* w, uint64_t n, const float* pos, const float
     PHYS_HIP_TRY(hipMemsetAsync(w->force.p, 0, 12 * n, s));
     PHYS_HIP_TRY(hipMemsetAsync(w->torque.p, 0, 12 * n, s));
     PHYS_HIP_TRY(hipMemcpyAsync(w->inv_inertia.p, h_inv.data(), 36 * n, hipMemcpyHostToDevice, s));
+    PHYS_HIP_TRY(hipMemcpyAsync(w->inv_inertia_diag.p, h_diag.data(), 16 * n, hipMemcpyHostToDevice, s));
     PHYS_HIP_TRY(hipMemcpyAsync(w->half_extent.p, h_he.data(), 12 * n, hipMemcpyHostToDevice, s));
     PHYS_HIP_TRY(hipMemcpyAsync(w->shape.p, h_shape.data(), 4 * n, hipMemcpyHostToDevice, s));
     PHYS_HIP_TRY(hipMemcpyAsync(w->global_id.p, h_gid.data(), 4 * n, hipMemcpyHostToDevice, s));

@@ -28,8 +28,10 @@ __device__ __forceinline__ void integrate_velocity(v3 F, v3 T, float mass, const
     const v3 L = v3_make(T.x * dt, T.y * dt, T.z * dt);
     v3 dw;
     if (DIAG) {
-        // off-diagonals are exactly zero: the gemv row sum reduces to the diagonal product
-        dw = v3_make(inv_inertia[9 * i + 0] * L.x, inv_inertia[9 * i + 4] * L.y, inv_inertia[9 * i + 8] * L.z);
+        // off-diagonals are exactly zero: the gemv row sum reduces to the diagonal product. `inv_inertia` is
+        // the compact diagonal array here (one float4 per body)
+        const float4 d = reinterpret_cast<const float4*>(inv_inertia)[i];
+        dw = v3_make(d.x * L.x, d.y * L.y, d.z * L.z);
     } else {
         m33 I;
 #pragma unroll
@@ -247,7 +249,7 @@ static void launch_full(phys_world* w, const StepParams& sp) {
     const dim3 g = grid_for(w->n), b(256);
 #define LAUNCH(D, E)                                                                                              \
     hipLaunchKernelGGL((k_step_full<FORCES, GRAVITY, D, E>), g, b, 0, w->stream, sp, w->pos.p, w->rot.p, w->vel.p, \
-                       w->force.p, w->torque.p, w->inv_inertia.p)
+                       w->force.p, w->torque.p, D ? w->inv_inertia_diag.p : w->inv_inertia.p)
     PHYS_PROF(w, PHYS_STAGE_STEP_FULL);
     if (diag && exact) LAUNCH(true, true);
     else if (diag) LAUNCH(true, false);
@@ -273,7 +275,7 @@ void launch_step_velocity_aabb(phys_world* w, float dt, bool gravity) {
     const float margin = w->cfg.contact_margin;
 #define LAUNCH(F, G, D)                                                                                            \
     hipLaunchKernelGGL((k_step_velocity_aabb<F, G, D>), g, b, 0, w->stream, sp, w->pos.p, w->rot.p, w->vel.p,      \
-                       w->force.p, w->torque.p, w->inv_inertia.p, w->shape.p,                \
+                       w->force.p, w->torque.p, D ? w->inv_inertia_diag.p : w->inv_inertia.p, w->shape.p,                \
                        w->half_extent.p, margin, w->aabb.p, w->counters.p)
     const int sel = (w->forces_dirty ? 4 : 0) | (gravity ? 2 : 0) | (diag ? 1 : 0);
     PHYS_PROF(w, PHYS_STAGE_VELOCITY_AABB);

@@ -23,6 +23,11 @@ struct ColorTable {
 constexpr int kRowPlanesPerPoint = 10;  // rA xyz, rB xyz, normal mass, tangent mass 0/1, bias
 constexpr int kAccPlanesPerPoint = 3;   // pn, pt0, pt1
 
+// inverse inertia of one body. DIAG: every body's tensor is diagonal (the reference's only case: identity,
+// rigid_body.rs:71), stored as one float4 per body = 16 B and one sector per gather instead of 36 B / two.
+// The zero off-diagonals are put back, so the arithmetic is the general path's (only signed zeros can differ).
+template <bool DIAG>
+__device__ __forceinline__ m33 ld_inertia(const float* __restrict__ p, uint32_t i);
 __device__ __forceinline__ m33 ld_m33(const float* __restrict__ p, uint32_t i) {
     m33 M;
 #pragma unroll
@@ -84,7 +89,20 @@ __global__ __launch_bounds__(256) void k_rows_build(const StepCounters* __restri
     }
 }
 
+template <>
+__device__ __forceinline__ m33 ld_inertia<false>(const float* __restrict__ p, uint32_t i) { return ld_m33(p, i); }
+template <>
+__device__ __forceinline__ m33 ld_inertia<true>(const float* __restrict__ p, uint32_t i) {
+    const float4 d = reinterpret_cast<const float4*>(p)[i];
+    m33 M;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) M.m[k] = 0.0f;
+    M.m[0] = d.x; M.m[4] = d.y; M.m[8] = d.z;
+    return M;
+}
+
 // one manifold row d of the colour-major numbering: load, solve_manifold, store
+template <bool DIAG>
 __device__ __forceinline__ void solve_row(uint32_t d, uint64_t cap, float friction, const uint32_t* __restrict__ row_a,
                                           const uint32_t* __restrict__ row_b, const uint32_t* __restrict__ row_count,
                                           const float* __restrict__ row_normal, const float* __restrict__ row_data,
@@ -113,7 +131,7 @@ __device__ __forceinline__ void solve_row(uint32_t d, uint64_t cap, float fricti
             c.pn = 0.0f; c.pt[0] = 0.0f; c.pt[1] = 0.0f;
         }
     }
-    const m33 IA = ld_m33(inv_inertia, a);
+    const m33 IA = ld_inertia<DIAG>(inv_inertia, a);
     BodyVel A = ld_vel(vel, a);
     const float ima = A.inv_mass;
     v3 vA = A.v, wA = A.w;
@@ -123,7 +141,7 @@ __device__ __forceinline__ void solve_row(uint32_t d, uint64_t cap, float fricti
     float imb = 0.0f;
     v3 vB = v3_make(0.0f, 0.0f, 0.0f), wB = v3_make(0.0f, 0.0f, 0.0f);
     BodyVel B = A;
-    if (sm.has_b) { IB = ld_m33(inv_inertia, b); B = ld_vel(vel, b); imb = B.inv_mass; vB = B.v; wB = B.w; }
+    if (sm.has_b) { IB = ld_inertia<DIAG>(inv_inertia, b); B = ld_vel(vel, b); imb = B.inv_mass; vB = B.v; wB = B.w; }
     solve_manifold(&sm, friction, ima, &IA, imb, &IB, &vA, &wA, &vB, &wB);
     A.v = vA; A.w = wA;
     st_vel(vel, a, A);
@@ -138,6 +156,7 @@ __device__ __forceinline__ void solve_row(uint32_t d, uint64_t cap, float fricti
 }
 
 // one colour of one iteration; the row range comes from the device-side colour table
+template <bool DIAG>
 __global__ __launch_bounds__(256) void k_solve_color(const StepCounters* __restrict__ ctr, uint32_t col, uint64_t cap,
                                                      float friction, const uint32_t* __restrict__ row_a,
                                                      const uint32_t* __restrict__ row_b,
@@ -148,7 +167,7 @@ __global__ __launch_bounds__(256) void k_solve_color(const StepCounters* __restr
     if (ctr->overflow) return;
     const uint32_t start = ctr->color_start[col], end = ctr->color_start[col + 1];
     for (uint32_t d = start + blockIdx.x * blockDim.x + threadIdx.x; d < end; d += gridDim.x * blockDim.x)
-        solve_row(d, cap, friction, row_a, row_b, row_count, row_normal, row_data, row_acc, inv_inertia, vel);
+        solve_row<DIAG>(d, cap, friction, row_a, row_b, row_count, row_normal, row_data, row_acc, inv_inertia, vel);
 }
 
 // The colour classes [first, n_colours) of one iteration in ONE launch of ONE workgroup: colours in
@@ -157,6 +176,7 @@ __global__ __launch_bounds__(256) void k_solve_color(const StepCounters* __restr
 // colour, without paying a ~8 us launch for a few hundred manifolds. `first` is a host HINT (the small
 // colours of the previous step); any value gives the same result, only the speed changes.
 constexpr int kTailThreads = 512;  // 2 waves per SIMD: the row solve needs ~144 VGPRs, 1024 threads would spill
+template <bool DIAG>
 __global__ __launch_bounds__(kTailThreads) void k_solve_tail(const StepCounters* __restrict__ ctr, uint32_t first, uint64_t cap,
                                                             float friction, const uint32_t* __restrict__ row_a,
                                                             const uint32_t* __restrict__ row_b,
@@ -169,7 +189,7 @@ __global__ __launch_bounds__(kTailThreads) void k_solve_tail(const StepCounters*
     for (uint32_t col = first; col < last; ++col) {
         const uint32_t start = ctr->color_start[col], end = ctr->color_start[col + 1];
         for (uint32_t d = start + threadIdx.x; d < end; d += kTailThreads)
-            solve_row(d, cap, friction, row_a, row_b, row_count, row_normal, row_data, row_acc, inv_inertia, vel);
+            solve_row<DIAG>(d, cap, friction, row_a, row_b, row_count, row_normal, row_data, row_acc, inv_inertia, vel);
         __threadfence_block();
         __syncthreads();
     }
@@ -189,6 +209,7 @@ void launch_solver(phys_world* w, float dt) {
     hipStream_t s = w->stream;
     const uint64_t cap = w->max_manifolds;
     const dim3 tb(256);
+    const bool diag = w->all_diag_inertia;
     auto grid_for_count = [&](uint64_t count) {
         uint64_t b = (count * 5 / 4 + 255) / 256 + 1;
         const uint64_t hi = (cap + 255) / 256;
@@ -211,14 +232,24 @@ void launch_solver(phys_world* w, float dt) {
     for (uint32_t it = 0; it < w->cfg.solver_iterations; ++it) {
         for (uint32_t col = 0; col < big; ++col) {
             PHYS_PROF(w, PHYS_STAGE_SOLVE);
-            hipLaunchKernelGGL(k_solve_color, grid_for_count(h.color_count[col]), tb, 0, s, w->counters.p, col, cap, sp.friction,
-                               w->row_a.p, w->row_b.p, w->row_count.p, w->row_normal.p, w->row_data.p, w->row_acc.p,
-                               w->inv_inertia.p, w->vel.p);
+            if (diag)
+                hipLaunchKernelGGL(k_solve_color<true>, grid_for_count(h.color_count[col]), tb, 0, s, w->counters.p, col, cap, sp.friction,
+                                   w->row_a.p, w->row_b.p, w->row_count.p, w->row_normal.p, w->row_data.p, w->row_acc.p,
+                                   w->inv_inertia_diag.p, w->vel.p);
+            else
+                hipLaunchKernelGGL(k_solve_color<false>, grid_for_count(h.color_count[col]), tb, 0, s, w->counters.p, col, cap, sp.friction,
+                                   w->row_a.p, w->row_b.p, w->row_count.p, w->row_normal.p, w->row_data.p, w->row_acc.p,
+                                   w->inv_inertia.p, w->vel.p);
         }
         PHYS_PROF(w, PHYS_STAGE_SOLVE);
-        hipLaunchKernelGGL(k_solve_tail, dim3(1), dim3(kTailThreads), 0, s, w->counters.p, big, cap, sp.friction,
-                           w->row_a.p, w->row_b.p, w->row_count.p, w->row_normal.p, w->row_data.p, w->row_acc.p,
-                           w->inv_inertia.p, w->vel.p);
+        if (diag)
+            hipLaunchKernelGGL(k_solve_tail<true>, dim3(1), dim3(kTailThreads), 0, s, w->counters.p, big, cap, sp.friction,
+                               w->row_a.p, w->row_b.p, w->row_count.p, w->row_normal.p, w->row_data.p, w->row_acc.p,
+                               w->inv_inertia_diag.p, w->vel.p);
+        else
+            hipLaunchKernelGGL(k_solve_tail<false>, dim3(1), dim3(kTailThreads), 0, s, w->counters.p, big, cap, sp.friction,
+                               w->row_a.p, w->row_b.p, w->row_count.p, w->row_normal.p, w->row_data.p, w->row_acc.p,
+                               w->inv_inertia.p, w->vel.p);
     }
 }
 

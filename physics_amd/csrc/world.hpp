@@ -140,7 +140,7 @@ struct phys_world {
     bool grid_valid = false;  // bucket grid + AABBs of the last broad phase are on the device (halo entry points)
 
     // body SoA
-    phys::DevBuf<float> pos, rot, vel /* 8n: v.xyz inv_mass w.xyz mass */, force, torque, inv_inertia, half_extent, aabb;
+    phys::DevBuf<float> pos, rot, vel /* 8n: v.xyz inv_mass w.xyz mass */, force, torque, inv_inertia, inv_inertia_diag /* 4n, valid when all_diag_inertia */, half_extent, aabb;
     phys::DevBuf<uint32_t> shape;
     phys::DevBuf<uint32_t> global_id;
 
