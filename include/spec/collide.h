@@ -39,6 +39,14 @@ typedef struct {
     float depth[4];
 } manifold_t;
 
+/* per-lane scratch of the polygon clipper: 224 bytes. The HIP narrow phase keeps it in LDS (one slice per
+ * lane, odd dword stride) instead of private scratch memory; the oracle puts it on the stack. */
+typedef struct {
+    v3 polyA[8];
+    v3 polyB[8];
+    float dep[8];
+} clip_ws_t;
+
 PHYS_HD geom_t geom_make(v3 c, quat q, v3 h, uint32_t type) {
     geom_t g;
     g.c = c; g.h = h; g.type = type;
@@ -195,7 +203,7 @@ PHYS_HD void manifold_reduce(const v3* p, const float* depth, int n, v3 normal, 
 /* face contact: Ref's face (axis r, side sgn) against the most anti-parallel face of Inc.
  * Writes points and depths; manifold normal is set by the caller. */
 PHYS_HD void box_face_contact(const geom_t* Ref, const geom_t* Inc, int r, float sgn, float margin, v3 n_ab,
-                              manifold_t* m) {
+                              manifold_t* m, clip_ws_t* ws) {
     const v3 nref = v3_scale(m33_col(&Ref->R, r), sgn);
     /* incident face: axis of Inc most anti-parallel to nref */
     const float d0 = v3_dot(nref, m33_col(&Inc->R, 0));
@@ -209,7 +217,8 @@ PHYS_HD void box_face_contact(const geom_t* Ref, const geom_t* Inc, int r, float
     const v3 fc = v3_add(Inc->c, v3_scale(m33_col(&Inc->R, j), jsgn * v3_get(Inc->h, j)));
     const v3 e1 = v3_scale(m33_col(&Inc->R, j1), v3_get(Inc->h, j1));
     const v3 e2 = v3_scale(m33_col(&Inc->R, j2), v3_get(Inc->h, j2));
-    v3 polyA[8], polyB[8];
+    v3* polyA = ws->polyA;
+    v3* polyB = ws->polyB;
     polyA[0] = v3_add(v3_add(fc, e1), e2);
     polyA[1] = v3_add(v3_sub(fc, e1), e2);
     polyA[2] = v3_sub(v3_sub(fc, e1), e2);
@@ -222,8 +231,8 @@ PHYS_HD void box_face_contact(const geom_t* Ref, const geom_t* Inc, int r, float
     n = clip_poly(polyB, n, Ref->c, v3_neg(u1), l1, polyA);
     n = clip_poly(polyA, n, Ref->c, u2, l2, polyB);
     n = clip_poly(polyB, n, Ref->c, v3_neg(u2), l2, polyA);
-    /* keep points at or below the reference face (+ margin) */
-    v3 cand[8]; float cdep[8]; int nc = 0;
+    /* keep points at or below the reference face (+ margin); the final polygon is in polyA, so polyB is free */
+    v3* cand = ws->polyB; float* cdep = ws->dep; int nc = 0;
     const float hr = v3_get(Ref->h, r);
     for (int k = 0; k < 8; ++k) {
         if (k >= n) break;
@@ -233,7 +242,7 @@ PHYS_HD void box_face_contact(const geom_t* Ref, const geom_t* Inc, int r, float
     manifold_reduce(cand, cdep, nc, n_ab, m);
 }
 
-PHYS_HD void collide_box_box(const geom_t* A, const geom_t* B, float margin, manifold_t* m) {
+PHYS_HD void collide_box_box(const geom_t* A, const geom_t* B, float margin, manifold_t* m, clip_ws_t* ws) {
     const v3 d = v3_sub(B->c, A->c);
     float C[3][3], absC[3][3], tA[3], tB[3], hA[3], hB[3];
     hA[0] = A->h.x; hA[1] = A->h.y; hA[2] = A->h.z;
@@ -322,16 +331,16 @@ PHYS_HD void collide_box_box(const geom_t* A, const geom_t* B, float margin, man
         const float sgn = tB[bAxis] > 0.0f ? -1.0f : 1.0f;
         const v3 nref = v3_scale(m33_col(&B->R, bAxis), sgn); /* B -> A */
         m->normal = v3_neg(nref);
-        box_face_contact(B, A, bAxis, sgn, margin, m->normal, m);
+        box_face_contact(B, A, bAxis, sgn, margin, m->normal, m, ws);
     } else {
         const float sgn = tA[aAxis] < 0.0f ? -1.0f : 1.0f;
         m->normal = v3_scale(m33_col(&A->R, aAxis), sgn); /* A -> B */
-        box_face_contact(A, B, aAxis, sgn, margin, m->normal, m);
+        box_face_contact(A, B, aAxis, sgn, margin, m->normal, m, ws);
     }
 }
 
 /* body-body manifold for the ordered pair (A = lower index, B = higher index) */
-PHYS_HD void collide_pair(const geom_t* A, const geom_t* B, float margin, manifold_t* m) {
+PHYS_HD void collide_pair(const geom_t* A, const geom_t* B, float margin, manifold_t* m, clip_ws_t* ws) {
     manifold_clear(m);
     if (A->type == PHYS_SPEC_SHAPE_SPHERE && B->type == PHYS_SPEC_SHAPE_SPHERE) {
         collide_sphere_sphere(A, B, margin, m);
@@ -341,13 +350,13 @@ PHYS_HD void collide_pair(const geom_t* A, const geom_t* B, float margin, manifo
         collide_sphere_box_raw(B, A, margin, m);
         m->normal = v3_neg(m->normal);
     } else if (A->type == PHYS_SPEC_SHAPE_BOX && B->type == PHYS_SPEC_SHAPE_BOX) {
-        collide_box_box(A, B, margin, m);
+        collide_box_box(A, B, margin, m, ws);
     }
 }
 
 /* body against the ground plane y = ground (normal +y). Manifold has A = body, B = ground, so the
  * A -> B normal is (0,-1,0). */
-PHYS_HD void collide_ground(const geom_t* A, float ground, float margin, manifold_t* m) {
+PHYS_HD void collide_ground(const geom_t* A, float ground, float margin, manifold_t* m, clip_ws_t* ws) {
     manifold_clear(m);
     m->normal = v3_make(0.0f, -1.0f, 0.0f);
     if (A->type == PHYS_SPEC_SHAPE_SPHERE) {
@@ -358,7 +367,7 @@ PHYS_HD void collide_ground(const geom_t* A, float ground, float margin, manifol
         m->pt[0] = v3_make(A->c.x, bottom + 0.5f * depth, A->c.z);
         m->depth[0] = depth;
     } else if (A->type == PHYS_SPEC_SHAPE_BOX) {
-        v3 cand[8]; float cdep[8]; int nc = 0;
+        v3* cand = ws->polyA; float* cdep = ws->dep; int nc = 0;
         const v3 ex = v3_scale(m33_col(&A->R, 0), A->h.x);
         const v3 ey = v3_scale(m33_col(&A->R, 1), A->h.y);
         const v3 ez = v3_scale(m33_col(&A->R, 2), A->h.z);

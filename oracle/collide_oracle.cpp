@@ -116,7 +116,8 @@ void CollisionWorld::narrowphase(const std::vector<RigidBody>& bodies) {
         const geom_t ga = geom_of(bodies[a], &half_extent[3 * a], shape_type[a]);
         const geom_t gb = geom_of(bodies[b], &half_extent[3 * b], shape_type[b]);
         manifold_t m;
-        collide_pair(&ga, &gb, margin, &m);
+        clip_ws_t ws;
+        collide_pair(&ga, &gb, margin, &m, &ws);
         if (m.count > 0) {
             Manifold M{a, b, m.normal, m.count, {m.pt[0], m.pt[1], m.pt[2], m.pt[3]}, {m.depth[0], m.depth[1], m.depth[2], m.depth[3]}};
             manifolds.push_back(M);
@@ -128,7 +129,8 @@ void CollisionWorld::narrowphase(const std::vector<RigidBody>& bodies) {
             if (shape_type[i] == PHYS_SHAPE_NONE) continue;
             const geom_t ga = geom_of(bodies[i], &half_extent[3 * i], shape_type[i]);
             manifold_t m;
-            collide_ground(&ga, ground, margin, &m);
+            clip_ws_t ws;
+            collide_ground(&ga, ground, margin, &m, &ws);
             if (m.count > 0) {
                 Manifold M{(uint32_t)i, PHYS_GROUND_ID, m.normal, m.count, {m.pt[0], m.pt[1], m.pt[2], m.pt[3]}, {m.depth[0], m.depth[1], m.depth[2], m.depth[3]}};
                 manifolds.push_back(M);

@@ -24,8 +24,9 @@ __device__ __forceinline__ geom_t load_geom(uint32_t i, const float* __restrict_
     return geom_make(ld3(pos, i), q, ld3(half_extent, i), shape[i]);
 }
 
-constexpr int kNpThreads = 256;
-
+// kNpThreads: 128 for small scenes (latency-bound: more workgroups in flight, the LDS slice of the clipper
+// halves), 256 for large ones (throughput-bound: fewer, fuller workgroups)
+template <int kNpThreads>
 __global__ __launch_bounds__(kNpThreads) void k_narrowphase(
     uint32_t n_ground /* bodies tested against the plane (0 = no ground) */, const uint32_t* __restrict__ pairs,
     uint64_t max_pairs, const float* __restrict__ pos, const float* __restrict__ rot,
@@ -36,6 +37,11 @@ __global__ __launch_bounds__(kNpThreads) void k_narrowphase(
     StepCounters* __restrict__ ctr) {
     __shared__ uint32_t wcount[kNpThreads / 64], wpts[kNpThreads / 64], wground[kNpThreads / 64];
     __shared__ uint32_t block_base;
+    // polygon-clipper scratch in LDS: one 56-dword slice per lane at an odd (57) dword stride, so the lanes of
+    // a wave hit distinct banks; private scratch memory would go through L1/L2 instead
+    constexpr int kWsStride = sizeof(clip_ws_t) / 4 + 1;
+    __shared__ float ws_lds[kNpThreads * kWsStride];
+    clip_ws_t* ws = reinterpret_cast<clip_ws_t*>(ws_lds + threadIdx.x * kWsStride);
     const uint32_t np_raw = ctr->n_pairs;
     const uint32_t n_pairs = (uint64_t)np_raw < max_pairs ? np_raw : (uint32_t)max_pairs;
     const uint32_t total = n_ground + n_pairs;
@@ -49,14 +55,14 @@ __global__ __launch_bounds__(kNpThreads) void k_narrowphase(
             a = idx;
             if (shape[a] != PHYS_SPEC_SHAPE_NONE) {
                 const geom_t ga = load_geom(a, pos, rot, half_extent, shape);
-                collide_ground(&ga, ground, margin, &m);
+                collide_ground(&ga, ground, margin, &m, ws);
             }
         } else if (idx < total) {
             const uint2 pr = reinterpret_cast<const uint2*>(pairs)[idx - n_ground];
             a = pr.x; b = pr.y;
             const geom_t ga = load_geom(a, pos, rot, half_extent, shape);
             const geom_t gb = load_geom(b, pos, rot, half_extent, shape);
-            collide_pair(&ga, &gb, margin, &m);
+            collide_pair(&ga, &gb, margin, &m, ws);
         }
         const bool has = m.count > 0;
         const unsigned long long mask = __ballot(has);
@@ -360,15 +366,22 @@ void launch_narrowphase(phys_world* w) {
     if (n == 0) return;
     const uint32_t n_ground = (w->cfg.flags & PHYS_FLAG_GROUND_PLANE) ? n : 0u;
     const uint64_t work = (uint64_t)n_ground + w->max_pairs;
-    uint64_t blocks = (work + kNpThreads - 1) / kNpThreads;
-    if (blocks > 256 * 16) blocks = 256 * 16;
     // colouring state of the step: used masks + three rotating priority buffers (one memset); the narrow
     // phase publishes round 0's per-body maxima as it emits manifolds
     { PHYS_PROF(w, PHYS_STAGE_COLOR); (void)hipMemsetAsync(w->color_state.p, 0, (size_t)4 * n * 8, w->stream); }
-    { PHYS_PROF(w, PHYS_STAGE_NARROW); hipLaunchKernelGGL(k_narrowphase, dim3((unsigned)blocks), dim3(kNpThreads), 0, w->stream, n_ground, w->pairs.p,
-                       w->max_pairs, w->pos.p, w->rot.p, w->half_extent.p, w->shape.p, w->cfg.contact_margin,
-                       w->cfg.ground_height, w->max_manifolds, w->man_a.p, w->man_b.p, w->man_count.p, w->man_color.p,
-                       w->man_normal.p, w->man_points.p, w->man_prio.p, w->color_state.p + n, w->counters.p); }
+    PHYS_PROF(w, PHYS_STAGE_NARROW);
+#define PHYS_NP_LAUNCH(T)                                                                                              \
+    do {                                                                                                               \
+        uint64_t blocks = (work + T - 1) / T;                                                                          \
+        if (blocks > 256 * 16) blocks = 256 * 16;                                                                      \
+        hipLaunchKernelGGL((k_narrowphase<T>), dim3((unsigned)blocks), dim3(T), 0, w->stream, n_ground, w->pairs.p,    \
+                           w->max_pairs, w->pos.p, w->rot.p, w->half_extent.p, w->shape.p, w->cfg.contact_margin,      \
+                           w->cfg.ground_height, w->max_manifolds, w->man_a.p, w->man_b.p, w->man_count.p,             \
+                           w->man_color.p, w->man_normal.p, w->man_points.p, w->man_prio.p, w->color_state.p + n,      \
+                           w->counters.p);                                                                             \
+    } while (0)
+    if (n <= 200000u) PHYS_NP_LAUNCH(128); else PHYS_NP_LAUNCH(256);
+#undef PHYS_NP_LAUNCH
 }
 
 static void launch_color_round(phys_world* w, uint32_t round, unsigned blocks) {
