@@ -29,8 +29,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s ach
 
 KERNEL_OF_STAGE = {
     "step_full": "k_step_full", "velocity_aabb": "k_step_velocity_aabb", "grid": "k_cell_assign+scan+k_scatter",
-    "pairs": "k_find_pairs", "narrow": "k_narrowphase", "color": "k_color_top+k_color_assign",
-    "rows": "k_row_src+k_rows_build", "solve": "k_solve_color", "position": "k_step_position",
+    "pairs": "k_find_pairs", "narrow": "k_narrowphase", "color": "k_color_round",
+    "rows": "k_rows_build+k_color_hist+k_color_offsets+k_color_place", "solve": "k_solve_color", "position": "k_step_position",
 }
 
 
@@ -59,6 +59,19 @@ def stage_bytes(stage, st, iters):
     return 0
 
 
+def pmc_traffic(workload_key, kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/pmc_traffic.json, produced by
+    profiles/collect_pmc.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same script)."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if not os.path.exists(path):
+        return None
+    table = json.load(open(path)).get(workload_key, {})
+    for name, row in table.items():
+        if name.split("<")[0].endswith(kernel):
+            return row["traffic_bytes"]
+    return None
+
+
 def stats_dict(s):
     return {f: int(getattr(s, f)) for f in ("n_bodies", "n_pairs", "n_manifolds", "n_contacts", "n_colors",
                                             "color_rounds", "n_ground_manifolds")}
@@ -85,7 +98,7 @@ def run_timed(world, steps, dist=None, halo=None):
     return time.perf_counter() - t0
 
 
-def profile_pass(world, steps, iters):
+def profile_pass(world, steps, iters, workload_key="c2"):
     """K more steps with per-launch HIP events; returns the roofline object of the dominant kernel and
     the per-stage table."""
     from physics_amd.scenes import DT_NANOS
@@ -109,7 +122,8 @@ def profile_pass(world, steps, iters):
     achieved = per_launch / dur_s / 1e9 if dur_s > 0 else 0.0
     total_bytes = sum(stage_bytes(s, st, iters) for s in kernel_stages)
     roof = {"bound": "hbm", "kernel": KERNEL_OF_STAGE[dom], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+            "traffic": pmc_traffic(workload_key, KERNEL_OF_STAGE[dom].split("+")[0]),
             "algorithmic_bytes_per_launch": int(per_launch), "avg_launch_us": round(table[dom]["avg_launch_us"], 3),
             "launches_per_step": round(launches, 2), "stage_share_of_device_time": round(
                 table[dom]["ms_per_step"] / max(sum(t["ms_per_step"] for t in table.values()), 1e-12), 3),
@@ -205,7 +219,7 @@ def main():
 
     out = None
     if rank == 0:
-        roof, table, st2 = profile_pass(world, min(args.steps, 100), iters) if halo is None else (None, None, st)
+        roof, table, st2 = profile_pass(world, min(args.steps, 100), iters, args.workload) if halo is None else (None, None, st)
         out = {
             "metric": "rigid_body_steps_per_sec", "value": round(n_total * args.steps / elapsed, 1),
             "unit": "body-steps/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
@@ -238,7 +252,7 @@ def main():
             w.sync()
             k = 60
             e = run_timed(w, k)
-            roof1, table1, st1 = profile_pass(w, 20, sc.solver_iterations)
+            roof1, table1, st1 = profile_pass(w, 20, sc.solver_iterations, "t1m")
             out["target_1m"] = {"workload": sc.name, "n_bodies": sc.n, "preroll_steps": 100, "steps": k,
                                 "steps_per_sec": round(k / e, 2), "target_steps_per_sec": 60.0,
                                 "body_steps_per_sec": round(sc.n * k / e, 1), "scene_stats": st1, "roofline": roof1,
