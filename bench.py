@@ -30,7 +30,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s ach
 KERNEL_OF_STAGE = {
     "step_full": "k_step_full", "velocity_aabb": "k_step_velocity_aabb", "grid": "k_cell_assign+scan+k_scatter",
     "pairs": "k_find_pairs", "narrow": "k_narrowphase", "color": "k_color_round",
-    "rows": "k_rows_build+k_color_hist+k_color_offsets+k_color_place", "solve": "k_solve_color", "position": "k_step_position",
+    "rows": "k_rows_build+k_color_hist+k_color_offsets+k_color_place", "solve": "k_solve_color",
+    "solve_tail": "k_solve_tail", "position": "k_step_position",
 }
 
 
@@ -55,7 +56,9 @@ def stage_bytes(stage, st, iters):
     if stage == "rows":
         return 100 * m + 24 * m + 76 * k + 52 * (m + mb)
     if stage == "solve":
-        return iters * (24 * m + 64 * k + 88 * (m + mb))
+        # per body and iteration: v, w read 24 + written 24, inverse mass 4, inverse inertia diagonal 12
+        # (all benchmark scenes have diagonal tensors; 36 with a full tensor)
+        return iters * (24 * m + 64 * k + 64 * (m + mb))
     return 0
 
 
@@ -116,6 +119,18 @@ def profile_pass(world, steps, iters, workload_key="c2"):
     kernel_stages = [s for s in table if s in KERNEL_OF_STAGE]
     dom = max(kernel_stages, key=lambda s: table[s]["ms_per_step"])
     b_step = stage_bytes(dom, st, iters)
+    if dom == "solve" and "solve_tail" in table:
+        # k_solve_color only runs the colours that got a launch of their own; the trailing small colours
+        # (<= 512 manifolds each, at least two of them) are solved by k_solve_tail. Scale the stage's bytes by the
+        # share of manifolds in the individually launched colours (same rule as launch_solver).
+        counts = [int(c) for c in world.get_color_counts()[:st["n_colors"]]]
+        big = len(counts)
+        while big > 0 and counts[big - 1] <= 512:
+            big -= 1
+        if len(counts) - big < 2:
+            big = len(counts)
+        if sum(counts):
+            b_step = b_step * sum(counts[:big]) / sum(counts)
     launches = table[dom]["launches_per_step"]
     per_launch = b_step / max(launches, 1e-9)
     dur_s = table[dom]["avg_launch_us"] * 1e-6
@@ -167,11 +182,19 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    # PHYS_BENCH_REHEARSAL=1: rehearse the N > 1 flow on a ONE-GPU box - every rank uses GPU 0, the
+    # collective runs over gloo on pinned host buffers (which the halo kernels read / write directly).
+    rehearsal = os.environ.get("PHYS_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     if world_size > 1:
         import torch.distributed as dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist_mod.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist_mod.init_process_group("gloo")
+        else:
+            dist_mod.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         dist = dist_mod
     else:
         torch.cuda.set_device(local_rank)
@@ -184,7 +207,7 @@ def main():
         scene = scenes.SCENES[args.workload]()
     else:
         from physics_amd import sharding
-        scene, halo = sharding.make_rank_scene(args.workload, rank, world_size, dist, local_rank)
+        scene, halo = sharding.make_rank_scene(args.workload, rank, world_size, dist, local_rank, pinned_host=rehearsal)
     world = physics_amd.World(scene.config(device=local_rank))
     scene.populate(world)
     if halo is not None:
@@ -204,14 +227,14 @@ def main():
 
     elapsed = run_timed(world, args.steps, dist, halo)
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else f"cuda:{local_rank}")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     st = stats_dict(world.get_stats())
     n_total = scene.n * n_gpus
     pairs_local = st["n_pairs"] + (halo.last_cross_pairs if halo is not None else 0)
     if dist is not None:
-        t = torch.tensor([pairs_local], dtype=torch.float64, device=f"cuda:{local_rank}")
+        t = torch.tensor([pairs_local], dtype=torch.float64, device="cpu" if rehearsal else f"cuda:{local_rank}")
         dist.all_reduce(t)
         pairs_total = float(t.item())
     else:
@@ -219,7 +242,8 @@ def main():
 
     out = None
     if rank == 0:
-        roof, table, st2 = profile_pass(world, min(args.steps, 100), iters, args.workload) if halo is None else (None, None, st)
+        # rank 0 profiles its own slab (no collective inside: the other ranks wait at the final barrier)
+        roof, table, st2 = profile_pass(world, min(args.steps, 100), iters, args.workload)
         out = {
             "metric": "rigid_body_steps_per_sec", "value": round(n_total * args.steps / elapsed, 1),
             "unit": "body-steps/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,

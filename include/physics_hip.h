@@ -156,6 +156,8 @@ int32_t phys_get_manifolds(phys_world* w, uint32_t* ids_out /*2*cap*/, uint32_t*
                            float* normals_out /*3*cap*/, float* points_out /*16*cap*/, uint64_t cap,
                            uint64_t* n_manifolds);
 int32_t phys_get_stats(phys_world* w, phys_stats* out);
+/* manifolds per solver colour of the last update (64 entries) */
+int32_t phys_get_color_counts(phys_world* w, uint32_t* counts_out /*64*/);
 
 /* --- per-stage device timing (HIP events on the world's stream), for bench.py's roofline --- */
 #define PHYS_STAGE_STEP_FULL 0u     /* gravity + RigidBody::step, one kernel (no collisions) */
@@ -169,6 +171,7 @@ int32_t phys_get_stats(phys_world* w, phys_stats* out);
 #define PHYS_STAGE_POSITION 8u      /* position half */
 #define PHYS_STAGE_CONSTRAINTS 9u   /* constraint assembly + CG (A3-A7) */
 #define PHYS_STAGE_MISC 10u         /* memsets, halo */
+#define PHYS_STAGE_SOLVE_TAIL 11u   /* k_solve_tail: the small colours of one iteration in one workgroup */
 #define PHYS_STAGE_COUNT 12u
 typedef struct phys_profile {
     double ms[PHYS_STAGE_COUNT];         /* summed device time per stage since enable */

@@ -68,7 +68,7 @@ class PhysStats(C.Structure):
 
 STAGE_COUNT = 12
 STAGE_NAMES = ["step_full", "velocity_aabb", "grid", "pairs", "narrow", "color", "rows", "solve", "position",
-               "constraints", "misc", "unused"]
+               "constraints", "misc", "solve_tail"]
 
 
 class PhysProfile(C.Structure):
@@ -145,6 +145,7 @@ PROTOTYPES = {
     "phys_get_aabbs": (C.c_int32, [C.c_void_p, f32p]),
     "phys_get_manifolds": (C.c_int32, [C.c_void_p, u32p, u32p, f32p, f32p, C.c_uint64, u64p]),
     "phys_get_stats": (C.c_int32, [C.c_void_p, C.POINTER(PhysStats)]),
+    "phys_get_color_counts": (C.c_int32, [C.c_void_p, u32p]),
     "phys_profile_enable": (C.c_int32, [C.c_void_p, C.c_int32]),
     "phys_profile_get": (C.c_int32, [C.c_void_p, C.POINTER(PhysProfile)]),
     "phys_get_device_view": (C.c_int32, [C.c_void_p, C.POINTER(PhysDeviceView)]),

@@ -492,6 +492,14 @@ int32_t phys_get_stats(phys_world* w, phys_stats* out) {
     return PHYS_OK;
 }
 
+int32_t phys_get_color_counts(phys_world* w, uint32_t* counts_out) {
+    ENTER(w);
+    if (!counts_out) return fail(PHYS_ERR_INVALID_ARG, "null output");
+    int32_t rc = fetch_counters(w); if (rc) return rc;
+    for (int k = 0; k < kMaxColors; ++k) counts_out[k] = k < (int)w->h_counters->n_colors ? w->h_counters->color_count[k] : 0u;
+    return PHYS_OK;
+}
+
 int32_t phys_profile_enable(phys_world* w, int32_t on) {
     ENTER(w);
     PHYS_HIP_TRY(hipStreamSynchronize(w->stream));

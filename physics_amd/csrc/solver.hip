@@ -241,7 +241,7 @@ void launch_solver(phys_world* w, float dt) {
                                    w->row_a.p, w->row_b.p, w->row_count.p, w->row_normal.p, w->row_data.p, w->row_acc.p,
                                    w->inv_inertia.p, w->vel.p);
         }
-        PHYS_PROF(w, PHYS_STAGE_SOLVE);
+        PHYS_PROF(w, PHYS_STAGE_SOLVE_TAIL);
         if (diag)
             hipLaunchKernelGGL(k_solve_tail<true>, dim3(1), dim3(kTailThreads), 0, s, w->counters.p, big, cap, sp.friction,
                                w->row_a.p, w->row_b.p, w->row_count.p, w->row_normal.p, w->row_data.p, w->row_acc.p,

@@ -63,7 +63,7 @@ class HaloExchange:
     """Per-step boundary exchange of one rank. `dist` is torch.distributed (already initialised);
     `device` is the torch device the record buffers live on ("cuda:k" for RCCL, "cpu" for gloo)."""
 
-    def __init__(self, dist, rank, world_size, device, cap):
+    def __init__(self, dist, rank, world_size, device, cap, pinned_host=False):
         import torch
         self.torch = torch
         self.dist = dist
@@ -71,8 +71,12 @@ class HaloExchange:
         self.world_size = world_size
         self.cap = int(cap)
         self.device = device
-        self.send = torch.empty((self.cap, RECORD_FLOATS), dtype=torch.float32, device=device)
-        self.recv = torch.empty((world_size, self.cap, RECORD_FLOATS), dtype=torch.float32, device=device)
+        kw = dict(dtype=torch.float32, device=device)
+        if pinned_host:  # host memory the GPU can address (rehearsal of the N > 1 flow over gloo on one GPU)
+            kw = dict(dtype=torch.float32, device="cpu", pin_memory=True)
+            self.device = "cpu"
+        self.send = torch.empty((self.cap, RECORD_FLOATS), **kw)
+        self.recv = torch.empty((world_size, self.cap, RECORD_FLOATS), **kw)
         self.x_lo = self.x_hi = 0.0
         self.reach = 0.0
         self.last_cross_pairs = 0
@@ -124,10 +128,10 @@ class _BenchHalo:
         return self.last_cross_pairs
 
 
-def make_rank_scene(workload, rank, world_size, dist, local_rank):
+def make_rank_scene(workload, rank, world_size, dist, local_rank, pinned_host=False):
     sc, x_lo, x_hi, gids = rank_scene(workload, rank, world_size)
     # boundary layers: two lattice layers per face is generous; 4x headroom
     ny_nz = sc.n // {"c1": 4, "c2": 25, "c3": 50, "c4": 100, "c5": 16, "t1m": 100}[workload]
     cap = max(4096, 16 * ny_nz)
-    halo = HaloExchange(dist, rank, world_size, f"cuda:{local_rank}", cap)
+    halo = HaloExchange(dist, rank, world_size, f"cuda:{local_rank}", cap, pinned_host=pinned_host)
     return sc, _BenchHalo(halo, x_lo, x_hi, gids)

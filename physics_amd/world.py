@@ -171,6 +171,11 @@ class World:
                                                  C.byref(n)))
         return ids, counts, normals, points
 
+    def get_color_counts(self):
+        out = np.zeros(64, np.uint32)
+        self._ck(self.lib.phys_get_color_counts(self.h, _p(out, u32p)))
+        return out
+
     def profile_enable(self, on=True):
         self._ck(self.lib.phys_profile_enable(self.h, int(on)))
 

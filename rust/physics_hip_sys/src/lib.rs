@@ -91,6 +91,7 @@ extern "C" {
     pub fn phys_get_manifolds(w: *mut phys_world, ids_out: *mut u32, counts_out: *mut u32, normals_out: *mut f32,
                               points_out: *mut f32, cap: u64, n_manifolds: *mut u64) -> i32;
     pub fn phys_get_stats(w: *mut phys_world, out: *mut phys_stats) -> i32;
+    pub fn phys_get_color_counts(w: *mut phys_world, counts_out: *mut u32) -> i32;
     pub fn phys_set_global_ids(w: *mut phys_world, global_ids: *const u32) -> i32;
     pub fn phys_halo_pack(w: *mut phys_world, x_lo: f32, x_hi: f32, reach: f32, dev_records_out: *mut c_void, cap: u64,
                           n_records: *mut u64) -> i32;
