@@ -232,7 +232,7 @@ def main():
         elapsed = float(t.item())
     st = stats_dict(world.get_stats())
     n_total = scene.n * n_gpus
-    pairs_local = st["n_pairs"] + (halo.last_cross_pairs if halo is not None else 0)
+    pairs_local = st["n_pairs"] + (int(world.get_stats().n_cross_pairs) if halo is not None else 0)
     if dist is not None:
         t = torch.tensor([pairs_local], dtype=torch.float64, device="cpu" if rehearsal else f"cuda:{local_rank}")
         dist.all_reduce(t)

@@ -85,7 +85,8 @@ typedef struct phys_stats {
     uint32_t overflow;      /* sticky capacity overflow flags */
     uint32_t n_ground_manifolds; /* manifolds against the ground plane (subset of n_manifolds) */
     float max_extent;       /* largest fattened-AABB edge of the last broad phase (the grid cell is 1.001x this) */
-    uint32_t reserved;
+    uint32_t n_halo_records; /* records written by the last phys_halo_pack */
+    uint64_t n_cross_pairs;  /* cross-rank pairs found by the last phys_halo_pairs */
 } phys_stats;
 
 /* reference defaults (see phys_config field comments) */
@@ -199,14 +200,19 @@ int32_t phys_get_device_view(phys_world* w, phys_device_view* out);
  * 32 B: {min xyz, max xyz, global id, pad}. phys_halo_pack writes to DEVICE memory the records of
  * owned bodies whose fattened AABB reaches outside [x_lo + reach, x_hi - reach] and returns the count;
  * reach must be >= the largest AABB edge on ANY rank (all-reduce phys_stats.max_extent), reach <= 0
- * means this rank's own grid cell. Both calls use the AABBs / grid of the last update or phys_broadphase. phys_halo_pairs takes the gathered records of the OTHER ranks (device
+ * means this rank's own grid cell. Both calls use the AABBs / grid of the last update or phys_broadphase.
+ * phys_halo_pack first fills the whole buffer with 0xFF (empty slot = global id 0xFFFFFFFF). phys_halo_pairs
+ * ignores records [skip_first, skip_first + skip_count): the caller's own block of an all-gathered buffer.
+ * With n_records / n_cross_pairs == NULL both calls only ENQUEUE work on the world's stream and return
+ * (no host synchronisation; phys_get_stats reports the counts later): the per-step exchange then costs no
+ * host round trip when the collective is enqueued on the same stream (phys_device_view.stream). phys_halo_pairs takes the gathered records of the OTHER ranks (device
  * memory) and appends owned-vs-remote candidate pairs (local index, global id of the remote body)
  * under the ownership rule "emitted by the rank owning the body with the smaller global id". */
 int32_t phys_set_global_ids(phys_world* w, const uint32_t* global_ids /*n*/);
 int32_t phys_halo_pack(phys_world* w, float x_lo, float x_hi, float reach, void* dev_records_out, uint64_t cap,
                        uint64_t* n_records);
-int32_t phys_halo_pairs(phys_world* w, const void* dev_remote_records, uint64_t n_remote,
-                        uint64_t* n_cross_pairs);
+int32_t phys_halo_pairs(phys_world* w, const void* dev_remote_records, uint64_t n_remote, uint64_t skip_first,
+                        uint64_t skip_count, uint64_t* n_cross_pairs);
 int32_t phys_get_cross_pairs(phys_world* w, uint32_t* pairs_out /*2*cap*/, uint64_t cap, uint64_t* n_pairs);
 
 #ifdef __cplusplus

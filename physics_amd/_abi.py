@@ -62,7 +62,8 @@ class PhysStats(C.Structure):
         ("overflow", C.c_uint32),
         ("n_ground_manifolds", C.c_uint32),
         ("max_extent", C.c_float),
-        ("reserved", C.c_uint32),
+        ("n_halo_records", C.c_uint32),
+        ("n_cross_pairs", C.c_uint64),
     ]
 
 
@@ -151,7 +152,7 @@ PROTOTYPES = {
     "phys_get_device_view": (C.c_int32, [C.c_void_p, C.POINTER(PhysDeviceView)]),
     "phys_set_global_ids": (C.c_int32, [C.c_void_p, u32p]),
     "phys_halo_pack": (C.c_int32, [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_uint64, u64p]),
-    "phys_halo_pairs": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, u64p]),
+    "phys_halo_pairs": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, u64p]),
     "phys_get_cross_pairs": (C.c_int32, [C.c_void_p, u32p, C.c_uint64, u64p]),
 }
 

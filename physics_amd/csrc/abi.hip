@@ -489,6 +489,8 @@ int32_t phys_get_stats(phys_world* w, phys_stats* out) {
     out->overflow = c.overflow;
     out->n_ground_manifolds = c.n_ground_manifolds;
     std::memcpy(&out->max_extent, &c.max_extent_bits, 4);
+    out->n_halo_records = c.n_halo;
+    out->n_cross_pairs = c.n_cross_pairs;
     return PHYS_OK;
 }
 
@@ -541,9 +543,10 @@ int32_t phys_halo_pack(phys_world* w, float x_lo, float x_hi, float reach, void*
     ENTER(w);
     return halo_pack(w, x_lo, x_hi, reach, dev_records_out, cap, n_records);
 }
-int32_t phys_halo_pairs(phys_world* w, const void* dev_remote_records, uint64_t n_remote, uint64_t* n_cross_pairs) {
+int32_t phys_halo_pairs(phys_world* w, const void* dev_remote_records, uint64_t n_remote, uint64_t skip_first,
+                        uint64_t skip_count, uint64_t* n_cross_pairs) {
     ENTER(w);
-    return halo_pairs(w, dev_remote_records, n_remote, n_cross_pairs);
+    return halo_pairs(w, dev_remote_records, n_remote, skip_first, skip_count, n_cross_pairs);
 }
 int32_t phys_get_cross_pairs(phys_world* w, uint32_t* pairs_out, uint64_t cap, uint64_t* n_pairs) {
     ENTER(w);

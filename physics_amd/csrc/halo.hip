@@ -74,7 +74,8 @@ __global__ __launch_bounds__(256) void k_halo_pack(uint32_t n, const float* __re
     }
 }
 
-__global__ __launch_bounds__(256) void k_halo_pairs(uint32_t n_remote, const HaloRecord* __restrict__ remote,
+__global__ __launch_bounds__(256) void k_halo_pairs(uint32_t n_remote, uint32_t skip_first, uint32_t skip_count,
+                                                    const HaloRecord* __restrict__ remote,
                                                     const uint32_t* __restrict__ bucket_start, uint32_t table_size,
                                                     uint32_t axis_mask, const uint32_t* __restrict__ sorted_ids,
                                                     const float* __restrict__ sorted_box,
@@ -85,7 +86,8 @@ __global__ __launch_bounds__(256) void k_halo_pairs(uint32_t n_remote, const Hal
     const float ext = __uint_as_float(ctr->max_extent_bits);
     const float cell = ext > 0.0f ? ext * 1.001f : 1.0f;
     const float inv_cell = 1.0f / cell;
-    const bool live = k < n_remote && remote[k].gid != 0xFFFFFFFFu;
+    // [skip_first, skip_first + skip_count) is this rank's own block of the gathered buffer
+    const bool live = k < n_remote && (k < skip_first || k >= skip_first + skip_count) && remote[k].gid != 0xFFFFFFFFu;
     aabb_t rb;
     uint32_t rgid = 0;
     int c0[3] = {0, 0, 0}, c1[3] = {-1, -1, -1};
@@ -158,16 +160,18 @@ static int32_t read_counters(phys_world* w) {
 }
 
 int32_t halo_pack(phys_world* w, float x_lo, float x_hi, float reach, void* dev_out, uint64_t cap, uint64_t* n_records) {
-    if (!dev_out || !n_records) { set_error("null argument"); return PHYS_ERR_INVALID_ARG; }
+    if (!dev_out) { set_error("null argument"); return PHYS_ERR_INVALID_ARG; }
     if (!(w->cfg.flags & PHYS_FLAG_COLLISIONS)) { set_error("world created without PHYS_FLAG_COLLISIONS"); return PHYS_ERR_UNSUPPORTED; }
     if (!w->grid_valid) { set_error("phys_halo_pack needs the AABBs of an update or phys_broadphase first"); return PHYS_ERR_UNSUPPORTED; }
     const uint32_t n = (uint32_t)w->n;
     PHYS_HIP_TRY(hipMemsetAsync(&w->counters.p->n_halo, 0, 4, w->stream));
+    PHYS_HIP_TRY(hipMemsetAsync(dev_out, 0xFF, cap * sizeof(HaloRecord), w->stream));  // unused slots: id 0xFFFFFFFF
     if (n) {
         PHYS_PROF(w, PHYS_STAGE_MISC);
         hipLaunchKernelGGL(k_halo_pack, dim3((n + 255) / 256), dim3(256), 0, w->stream, n, w->aabb.p, w->shape.p,
                            w->global_id.p, x_lo, x_hi, reach, (HaloRecord*)dev_out, cap, w->counters.p);
     }
+    if (!n_records) return PHYS_OK;  // asynchronous form: nothing returns to the host (phys_get_stats has the count)
     const int32_t rc = read_counters(w);
     if (rc != PHYS_OK) return rc;
     if (w->h_counters->overflow & 8u) { set_error("halo buffer capacity exceeded"); return PHYS_ERR_CAPACITY; }
@@ -175,8 +179,9 @@ int32_t halo_pack(phys_world* w, float x_lo, float x_hi, float reach, void* dev_
     return PHYS_OK;
 }
 
-int32_t halo_pairs(phys_world* w, const void* dev_remote, uint64_t n_remote, uint64_t* n_cross) {
-    if (!n_cross || (n_remote && !dev_remote)) { set_error("null argument"); return PHYS_ERR_INVALID_ARG; }
+int32_t halo_pairs(phys_world* w, const void* dev_remote, uint64_t n_remote, uint64_t skip_first, uint64_t skip_count,
+                   uint64_t* n_cross) {
+    if (n_remote && !dev_remote) { set_error("null argument"); return PHYS_ERR_INVALID_ARG; }
     if (!w->grid_valid) { set_error("phys_halo_pairs needs the grid of an update or phys_broadphase first"); return PHYS_ERR_UNSUPPORTED; }
     if (w->max_cross_pairs == 0) {
         w->max_cross_pairs = std::max<uint64_t>(4 * w->n, 4096);
@@ -189,10 +194,11 @@ int32_t halo_pairs(phys_world* w, const void* dev_remote, uint64_t n_remote, uin
         while ((1u << (3 * bits)) < T) ++bits;
         PHYS_PROF(w, PHYS_STAGE_MISC);
         hipLaunchKernelGGL(k_halo_pairs, dim3((unsigned)((n_remote + 255) / 256)), dim3(256), 0, w->stream,
-                           (uint32_t)n_remote, (const HaloRecord*)dev_remote, w->bucket_start.p, T, (1u << bits) - 1u,
+                           (uint32_t)n_remote, (uint32_t)skip_first, (uint32_t)skip_count, (const HaloRecord*)dev_remote, w->bucket_start.p, T, (1u << bits) - 1u,
                            w->sorted_ids.p, w->sorted_box.p, w->global_id.p, w->cross_pairs.p, w->max_cross_pairs,
                            w->counters.p);
     }
+    if (!n_cross) return PHYS_OK;  // asynchronous form
     const int32_t rc = read_counters(w);
     if (rc != PHYS_OK) return rc;
     if (w->h_counters->overflow & 8u) { set_error("cross-pair capacity exceeded"); return PHYS_ERR_CAPACITY; }

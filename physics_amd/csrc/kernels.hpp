@@ -75,6 +75,7 @@ void launch_constraint_phase(phys_world* w);
 
 // halo.hip
 int32_t halo_pack(phys_world* w, float x_lo, float x_hi, float reach, void* dev_out, uint64_t cap, uint64_t* n_records);
-int32_t halo_pairs(phys_world* w, const void* dev_remote, uint64_t n_remote, uint64_t* n_cross);
+int32_t halo_pairs(phys_world* w, const void* dev_remote, uint64_t n_remote, uint64_t skip_first, uint64_t skip_count,
+                   uint64_t* n_cross);
 
 }  // namespace phys

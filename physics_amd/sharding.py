@@ -81,13 +81,7 @@ class HaloExchange:
         self.reach = 0.0
         self.last_cross_pairs = 0
         self.last_halo_records = 0
-
-    def _invalidate(self, t):
-        t.view(self.torch.int32).fill_(-1)  # global id 0xFFFFFFFF = empty slot
-
-    def _sync(self):
-        if self.send.is_cuda:
-            self.torch.cuda.current_stream().synchronize()
+        self._ext_stream = None
 
     def attach(self, world, x_lo, x_hi, global_ids, half_extent, margin):
         self.x_lo, self.x_hi = float(x_lo), float(x_hi)
@@ -99,16 +93,28 @@ class HaloExchange:
 
     def exchange(self, world):
         """Call after world.update(): packs this rank's boundary AABBs, all-gathers them, and finds the
-        cross pairs this rank owns. Returns their count."""
-        self._invalidate(self.send)
-        self._sync()
+        cross pairs this rank owns.
+
+        Device buffers (RCCL): everything - pack kernel, all-gather, cross-pair kernel - is ENQUEUED on the
+        world's own HIP stream (wrapped as a torch ExternalStream so the collective is ordered on it); no
+        host synchronisation, returns None (phys_get_stats().n_cross_pairs has the count).
+        Host buffers (gloo, CPU tests / one-GPU rehearsal): synchronous, returns the cross-pair count."""
+        own_first = self.rank * self.cap
+        if self.send.is_cuda:
+            if self._ext_stream is None:
+                view = world.device_view()
+                self._ext_stream = self.torch.cuda.ExternalStream(view.stream, device=self.send.device)
+            world.halo_pack(self.x_lo, self.x_hi, self.reach, self.send.data_ptr(), self.cap, wait=False)
+            with self.torch.cuda.stream(self._ext_stream):
+                # ONE collective of fixed shape (latency-bound on xGMI: no count exchange, no ragged gather)
+                self.dist.all_gather_into_tensor(self.recv.view(-1, RECORD_FLOATS), self.send)
+            world.halo_pairs(self.recv.data_ptr(), self.world_size * self.cap, own_first, self.cap, wait=False)
+            self.last_cross_pairs = None
+            return None
         n = world.halo_pack(self.x_lo, self.x_hi, self.reach, self.send.data_ptr(), self.cap)
         self.last_halo_records = n
-        # ONE collective of fixed shape (latency-bound on xGMI: no count exchange, no ragged gather)
         self.dist.all_gather_into_tensor(self.recv.view(-1, RECORD_FLOATS), self.send)
-        self._invalidate(self.recv[self.rank])  # own records never pair with own bodies here
-        self._sync()
-        self.last_cross_pairs = world.halo_pairs(self.recv.data_ptr(), self.world_size * self.cap)
+        self.last_cross_pairs = world.halo_pairs(self.recv.data_ptr(), self.world_size * self.cap, own_first, self.cap)
         return self.last_cross_pairs
 
 

@@ -195,15 +195,17 @@ class World:
         ids = np.ascontiguousarray(ids, dtype=np.uint32)
         self._ck(self.lib.phys_set_global_ids(self.h, _p(ids, u32p)))
 
-    def halo_pack(self, x_lo, x_hi, reach, dev_ptr, cap):
+    def halo_pack(self, x_lo, x_hi, reach, dev_ptr, cap, wait=True):
+        """wait=False: enqueue only (no host synchronisation), returns None."""
         n = C.c_uint64()
-        self._ck(self.lib.phys_halo_pack(self.h, x_lo, x_hi, reach, C.c_void_p(dev_ptr), cap, C.byref(n)))
-        return n.value
+        self._ck(self.lib.phys_halo_pack(self.h, x_lo, x_hi, reach, C.c_void_p(dev_ptr), cap, C.byref(n) if wait else None))
+        return n.value if wait else None
 
-    def halo_pairs(self, dev_ptr, n_remote):
+    def halo_pairs(self, dev_ptr, n_remote, skip_first=0, skip_count=0, wait=True):
         n = C.c_uint64()
-        self._ck(self.lib.phys_halo_pairs(self.h, C.c_void_p(dev_ptr), n_remote, C.byref(n)))
-        return n.value
+        self._ck(self.lib.phys_halo_pairs(self.h, C.c_void_p(dev_ptr), n_remote, skip_first, skip_count,
+                                          C.byref(n) if wait else None))
+        return n.value if wait else None
 
     def get_cross_pairs(self):
         n = C.c_uint64()

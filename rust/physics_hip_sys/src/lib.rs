@@ -52,7 +52,8 @@ pub struct phys_stats {
     pub overflow: u32,
     pub n_ground_manifolds: u32,
     pub max_extent: f32,
-    pub reserved: u32,
+    pub n_halo_records: u32,
+    pub n_cross_pairs: u64,
 }
 
 #[repr(C)]
@@ -95,7 +96,7 @@ extern "C" {
     pub fn phys_set_global_ids(w: *mut phys_world, global_ids: *const u32) -> i32;
     pub fn phys_halo_pack(w: *mut phys_world, x_lo: f32, x_hi: f32, reach: f32, dev_records_out: *mut c_void, cap: u64,
                           n_records: *mut u64) -> i32;
-    pub fn phys_halo_pairs(w: *mut phys_world, dev_remote_records: *const c_void, n_remote: u64,
-                           n_cross_pairs: *mut u64) -> i32;
+    pub fn phys_halo_pairs(w: *mut phys_world, dev_remote_records: *const c_void, n_remote: u64, skip_first: u64,
+                           skip_count: u64, n_cross_pairs: *mut u64) -> i32;
     pub fn phys_get_cross_pairs(w: *mut phys_world, pairs_out: *mut u32, cap: u64, n_pairs: *mut u64) -> i32;
 }

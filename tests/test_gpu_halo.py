@@ -41,7 +41,7 @@ def test_pack_exchange_pairs_union_matches_single_world():
     for (sc, x_lo, x_hi, gids), w in zip(parts, worlds):
         p = w.broadphase()  # builds AABBs + grid on the device
         local.append(np.sort(gids[p], axis=1))
-        buf = torch.full((cap, 8), -1, dtype=torch.int32, device="cuda")
+        buf = torch.zeros((cap, 8), dtype=torch.int32, device="cuda")  # the pack call blanks it itself
         torch.cuda.synchronize()
         counts.append(w.halo_pack(x_lo, x_hi, reach, buf.data_ptr(), cap))
         bufs.append(buf)
@@ -85,3 +85,40 @@ def test_halo_after_update_uses_the_step_grid():
     halo_ids = set(buf[:n, 6].cpu().numpy().view(np.uint32).tolist())
     local = w.broadphase()
     assert n_back == sum(1 for a, b in local.tolist() if int(gids[b]) in halo_ids)
+
+
+def test_async_exchange_on_the_worlds_stream_with_rccl_world_size_1():
+    """The N > 1 production path of physics_amd.sharding.HaloExchange (pack kernel -> RCCL all-gather ->
+    cross-pair kernel, all enqueued on the world's own stream through torch.cuda.ExternalStream, no host
+    synchronisation) exercised with a one-rank RCCL group: the gathered buffer is this rank's own block, which
+    phys_halo_pairs must skip."""
+    import os
+    import socket
+    import torch
+    import torch.distributed as dist
+    import physics_amd
+    from physics_amd import scenes, sharding
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        sc, x_lo, x_hi, gids = sharding.rank_scene("c1", 0, 1, shape=(6, 5, 7, 2.03))
+        w = physics_amd.World(sc.config())
+        sc.populate(w)
+        halo = sharding.HaloExchange(dist, 0, 1, "cuda:0", cap=512)
+        halo.attach(w, x_lo, x_hi, gids, sc.half_extent, 0.02)
+        for _ in range(5):
+            w.update(scenes.DT_NANOS)
+            assert halo.exchange(w) is None  # asynchronous form
+        w.sync()
+        st = w.get_stats()
+        assert 0 < st.n_halo_records <= 512
+        assert st.n_cross_pairs == 0  # the only block in the gathered buffer is our own
+        # the records really went through the collective on the world's stream
+        got = halo.recv[0].cpu().numpy().view(np.uint32)[:, 6]
+        assert (got != 0xFFFFFFFF).sum() == st.n_halo_records
+        w.close()
+    finally:
+        dist.destroy_process_group()

@@ -39,20 +39,22 @@ class OracleHaloWorld:
         buf = (ctypes.c_float * (rows * 8)).from_address(ptr)
         return np.ctypeslib.as_array(buf).reshape(rows, 8)
 
-    def halo_pack(self, x_lo, x_hi, reach, ptr, cap):
+    def halo_pack(self, x_lo, x_hi, reach, ptr, cap, wait=True):
         a = self.o.get_aabbs()
         take = (a[:, 0] < np.float32(x_lo) + np.float32(reach)) | (a[:, 3] > np.float32(x_hi) - np.float32(reach))
         idx = np.nonzero(take)[0]
         assert len(idx) <= cap
         out = self._view(ptr, cap)
+        out.view(np.uint32)[:] = 0xFFFFFFFF  # phys_halo_pack blanks the whole buffer first
         out[:len(idx), :6] = a[idx]
         out[:len(idx), 6] = self.gids[idx].view(np.float32)
         out[:len(idx), 7] = 0
         return len(idx)
 
-    def halo_pairs(self, ptr, n_remote):
+    def halo_pairs(self, ptr, n_remote, skip_first=0, skip_count=0, wait=True):
         rec = self._view(ptr, n_remote)
         rg = rec[:, 6].copy().view(np.uint32)
+        rg[skip_first:skip_first + skip_count] = 0xFFFFFFFF  # own block of the gathered buffer
         a = self.o.get_aabbs()
         found = []
         for k in np.nonzero(rg != 0xFFFFFFFF)[0]:
