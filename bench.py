@@ -62,6 +62,20 @@ def stage_bytes(stage, st, iters):
     return 0
 
 
+def rocprof_avg_us(workload_key, kernel):
+    """Average kernel duration from the committed rocprofv3 --kernel-trace --stats summary of this same script
+    (profiles/r1_<workload>_kernel_stats.csv). HIP-event brackets (avg_launch_us) additionally contain the
+    dispatch of the launch (about 2-4 us), so they read higher than rocprof's begin-to-end kernel time."""
+    import csv
+    path = os.path.join(ROOT, "profiles", f"r1_{workload_key}_kernel_stats.csv")
+    if not os.path.exists(path):
+        return None
+    for row in csv.DictReader(open(path)):
+        if row["Name"].split("(")[0].split("<")[0].endswith(kernel):
+            return round(float(row["AverageNs"]) / 1e3, 3)
+    return None
+
+
 def pmc_traffic(workload_key, kernel):
     """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/pmc_traffic.json, produced by
     profiles/collect_pmc.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same script)."""
@@ -140,6 +154,7 @@ def profile_pass(world, steps, iters, workload_key="c2"):
             "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
             "traffic": pmc_traffic(workload_key, KERNEL_OF_STAGE[dom].split("+")[0]),
             "algorithmic_bytes_per_launch": int(per_launch), "avg_launch_us": round(table[dom]["avg_launch_us"], 3),
+            "avg_kernel_us_rocprofv3": rocprof_avg_us(workload_key, KERNEL_OF_STAGE[dom].split("+")[0]),
             "launches_per_step": round(launches, 2), "stage_share_of_device_time": round(
                 table[dom]["ms_per_step"] / max(sum(t["ms_per_step"] for t in table.values()), 1e-12), 3),
             "algorithmic_bytes_per_step_all_kernels": int(total_bytes)}
