@@ -408,8 +408,21 @@ void launch_coloring(phys_world* w) {
         if (want < blocks64) blocks64 = want ? want : 1;
     }
     const unsigned blocks = (unsigned)blocks64;
-    const uint32_t rounds = w->hint.valid ? w->hint.color_rounds + 1 : 10;  // k_color_finish covers a miss
-    for (uint32_t r = 0; r < rounds; ++r) launch_color_round(w, r, blocks);
+    uint32_t rounds = 0;
+    if (w->hint.valid) {
+        rounds = w->hint.color_rounds + 1;  // k_color_finish covers a miss
+        for (uint32_t r = 0; r < rounds; ++r) launch_color_round(w, r, blocks);
+    } else {
+        // first step after phys_set_bodies: nothing is known about the scene yet, so this one step asks the
+        // device (a single-workgroup finish / tail over millions of manifolds would take seconds)
+        for (int guard = 0; guard < 4096; ++guard) {
+            for (uint32_t k = 0; k < 8; ++k) launch_color_round(w, rounds++, blocks);
+            (void)hipMemcpyAsync(w->h_counters, w->counters.p, sizeof(StepCounters), hipMemcpyDeviceToHost, s);
+            (void)hipStreamSynchronize(s);
+            if (w->prof.on) w->prof.collect(s);
+            if (w->h_counters->n_uncolored == 0 || w->h_counters->overflow) break;
+        }
+    }
     { PHYS_PROF(w, PHYS_STAGE_COLOR); hipLaunchKernelGGL(k_color_finish, dim3(1), dim3(kColorThreads), 0, s, rounds, w->max_manifolds, w->man_a.p, w->man_b.p, w->man_color.p, w->man_prio.p, w->color_state.p, (uint64_t)n, w->counters.p); }
     // workgroups of the colour sort: sized from the hint (any value is correct: the kernels stride)
     uint32_t nb = kSortBlocksMax;
@@ -421,7 +434,21 @@ void launch_coloring(phys_world* w) {
     { PHYS_PROF(w, PHYS_STAGE_ROWS); hipLaunchKernelGGL(k_color_hist, dim3(nb), dim3(1024), 0, s, w->max_manifolds, w->man_color.p, w->color_block_hist.p, nb, w->counters.p); }
     { PHYS_PROF(w, PHYS_STAGE_ROWS); hipLaunchKernelGGL(k_color_offsets, dim3(1), dim3(1024), 0, s, w->color_block_hist.p, nb, w->counters.p); }
     { PHYS_PROF(w, PHYS_STAGE_ROWS); hipLaunchKernelGGL(k_color_place, dim3(nb), dim3(1024), 0, s, w->max_manifolds, w->man_color.p, w->color_block_hist.p, nb, w->row_src.p, w->counters.p); }
-    snapshot_counters_async(w);
+    if (!w->hint.valid) {
+        // ... and adopts the exact counters as the first hint (the solver launches right after use them)
+        (void)hipMemcpyAsync(w->h_counters, w->counters.p, sizeof(StepCounters), hipMemcpyDeviceToHost, s);
+        (void)hipStreamSynchronize(s);
+        const StepCounters& c = *w->h_counters;
+        if (!c.overflow) {
+            w->hint.valid = true;
+            w->hint.n_manifolds = c.n_manifolds;
+            w->hint.n_colors = c.n_colors;
+            w->hint.color_rounds = c.color_rounds;
+            for (int q = 0; q < kMaxColors; ++q) w->hint.color_count[q] = c.color_count[q];
+        }
+    } else {
+        snapshot_counters_async(w);
+    }
 }
 
 }  // namespace phys
