@@ -18,6 +18,11 @@
  *          an uncoloured manifold that is top at every dynamic body it touches takes the lowest
  *          colour not yet used at those bodies, and marks it used there.
  *   repeat until all are coloured. At most PHYS_MAX_COLORS colours.
+ *
+ * Persistent colouring (what makes a steady scene cheap): a manifold (a, b) that also existed in the previous
+ * update KEEPS its colour; the rounds above run over the NEW manifolds only, with `used` pre-seeded by the kept
+ * colours. Every PHYS_COLOR_CACHE_PERIOD-th update since the bodies were set, nothing is kept (the colour
+ * numbers are re-compacted). The colouring is thus a pure function of (previous colouring, manifold set).
  */
 #ifndef PHYS_SPEC_CONTACT_SOLVE_H
 #define PHYS_SPEC_CONTACT_SOLVE_H
@@ -25,6 +30,7 @@
 #include "collide.h"
 
 #define PHYS_MAX_COLORS 64
+#define PHYS_COLOR_CACHE_PERIOD 64
 
 typedef struct {
     float dt;

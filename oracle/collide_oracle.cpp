@@ -140,7 +140,12 @@ void CollisionWorld::narrowphase(const std::vector<RigidBody>& bodies) {
     }
 }
 
-void CollisionWorld::color_manifolds(size_t n_bodies) {
+// Colouring of one step (include/spec/contact_solve.h "persistent colouring"): a manifold that existed in
+// the previous update keeps its colour; only the new ones go through the Jones-Plassmann rounds, against
+// `used` masks pre-seeded with the kept colours. Every PHYS_COLOR_CACHE_PERIOD-th update (counted from
+// phys_set_bodies) nothing is kept. `persistent = false` (the collide_now test hook) neither reads nor updates
+// the cache.
+void CollisionWorld::color_manifolds(size_t n_bodies, bool persistent) {
     const size_t M = manifolds.size();
     const uint32_t UNCOLORED = 0xFFFFFFFFu;
     color.assign(M, UNCOLORED);
@@ -149,6 +154,19 @@ void CollisionWorld::color_manifolds(size_t n_bodies) {
     size_t remaining = M;
     n_colors = 0;
     color_rounds = 0;
+    const bool keep = persistent && (color_epoch % PHYS_COLOR_CACHE_PERIOD) != 0;
+    if (keep) {
+        for (size_t m = 0; m < M; ++m) {
+            const Manifold& mf = manifolds[m];
+            auto it = color_cache.find(((uint64_t)mf.a << 32) | mf.b);
+            if (it == color_cache.end()) continue;
+            color[m] = it->second;
+            used[mf.a] |= 1ull << it->second;
+            if (mf.b != PHYS_GROUND_ID) used[mf.b] |= 1ull << it->second;
+            n_colors = std::max(n_colors, it->second + 1);
+            --remaining;
+        }
+    }
     std::vector<size_t> winners;
     while (remaining > 0) {
         std::fill(top.begin(), top.end(), 0ull);
@@ -177,6 +195,12 @@ void CollisionWorld::color_manifolds(size_t n_bodies) {
         }
         remaining -= winners.size();
         ++color_rounds;
+    }
+    if (persistent) {
+        color_cache.clear();
+        color_cache.reserve(2 * M);
+        for (size_t m = 0; m < M; ++m) color_cache[((uint64_t)manifolds[m].a << 32) | manifolds[m].b] = color[m];
+        ++color_epoch;
     }
 }
 
@@ -234,7 +258,7 @@ void CollisionWorld::collide_and_solve(std::vector<RigidBody>& bodies, float dt)
     broadphase_grid();
     if (flags & PHYS_FLAG_BROADPHASE_ONLY) { manifolds.clear(); color.clear(); n_colors = 0; n_contacts = 0; return; }
     narrowphase(bodies);
-    color_manifolds(bodies.size());
+    color_manifolds(bodies.size(), true);
     solve(bodies, dt);
 }
 

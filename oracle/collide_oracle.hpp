@@ -8,6 +8,7 @@
 // independently organised computation of the same specification.
 #pragma once
 #include <cstdint>
+#include <unordered_map>
 #include <utility>
 #include <vector>
 
@@ -45,7 +46,9 @@ struct CollisionWorld {
     void broadphase_sweep();  // sort-and-sweep on x (independent check, O(N * layer))
     void broadphase_grid();   // uniform grid, O(N); same pair set
     void narrowphase(const std::vector<RigidBody>& bodies);
-    void color_manifolds(size_t n_bodies);
+    void color_manifolds(size_t n_bodies, bool persistent);
+    std::unordered_map<uint64_t, uint32_t> color_cache;  // (a << 32 | b) -> colour of the previous update
+    uint64_t color_epoch = 0;                            // updates since the bodies were set
     void solve(std::vector<RigidBody>& bodies, float dt);
     void collide_and_solve(std::vector<RigidBody>& bodies, float dt);
     std::vector<size_t> sorted_manifold_order() const;

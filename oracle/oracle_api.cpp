@@ -69,6 +69,8 @@ int32_t oracle_set_bodies(oracle_world* w, uint64_t n, const float* pos, const f
         w->state.entities.push_back(b);
     }
     w->state.previous_solution.reset();
+    w->col.color_cache.clear();
+    w->col.color_epoch = 0;
     return PHYS_OK;
 }
 
@@ -237,7 +239,7 @@ int32_t oracle_collide_now(oracle_world* w) {
     w->col.compute_aabbs(w->state.entities);
     w->col.broadphase_sweep();
     w->col.narrowphase(w->state.entities);
-    w->col.color_manifolds(w->state.entities.size());
+    w->col.color_manifolds(w->state.entities.size(), false);
     return PHYS_OK;
 }
 int32_t oracle_get_aabbs(oracle_world* w, float* out) {

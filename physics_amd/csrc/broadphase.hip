@@ -332,6 +332,14 @@ int32_t collision_alloc(phys_world* w) {
         PHYS_HIP_TRY(w->man_prio.resize(M));
         PHYS_HIP_TRY(w->color_state.resize(4 * n));
         PHYS_HIP_TRY(w->row_src.resize(M));
+        {
+            uint64_t cap = 4096;
+            while (cap < M + M / 2) cap <<= 1;
+            for (int t = 0; t < 2; ++t) { PHYS_HIP_TRY(w->ctab_keys[t].resize(cap)); PHYS_HIP_TRY(w->ctab_cols[t].resize(cap)); PHYS_HIP_TRY(w->ctab_slots[t].resize(M + 1)); w->ctab_fresh[t] = false; }
+            w->ctab_mask = (uint32_t)(cap - 1);
+            w->ctab_valid = false;
+            w->color_epoch = 0;
+        }
         PHYS_HIP_TRY(w->color_block_hist.resize((size_t)kMaxColors * 512));
         PHYS_HIP_TRY(w->row_a.resize(M)); PHYS_HIP_TRY(w->row_b.resize(M)); PHYS_HIP_TRY(w->row_count.resize(M));
         PHYS_HIP_TRY(w->row_normal.resize(3 * M));

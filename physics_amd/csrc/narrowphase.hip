@@ -33,9 +33,11 @@ __global__ __launch_bounds__(kNpThreads) void k_narrowphase(
     const float* __restrict__ half_extent, const uint32_t* __restrict__ shape, float margin, float ground,
     uint64_t max_manifolds, uint32_t* __restrict__ man_a, uint32_t* __restrict__ man_b,
     uint32_t* __restrict__ man_count, uint32_t* __restrict__ man_color, float* __restrict__ man_normal,
-    float* __restrict__ man_points, uint64_t* __restrict__ man_prio, unsigned long long* __restrict__ top0,
+    float* __restrict__ man_points, uint64_t* __restrict__ man_prio, unsigned long long* __restrict__ used,
+    unsigned long long* __restrict__ top0, const unsigned long long* __restrict__ cache_keys,
+    const uint32_t* __restrict__ cache_cols, uint32_t cache_mask /* 0 = keep nothing this update */,
     StepCounters* __restrict__ ctr) {
-    __shared__ uint32_t wcount[kNpThreads / 64], wpts[kNpThreads / 64], wground[kNpThreads / 64];
+    __shared__ uint32_t wcount[kNpThreads / 64], wpts[kNpThreads / 64], wground[kNpThreads / 64], wunc[kNpThreads / 64];
     __shared__ uint32_t block_base;
     // polygon-clipper scratch in LDS: one 56-dword slice per lane at an odd (57) dword stride, so the lanes of
     // a wave hit distinct banks; private scratch memory would go through L1/L2 instead
@@ -86,7 +88,6 @@ __global__ __launch_bounds__(kNpThreads) void k_narrowphase(
                 bb = atomicAdd(&ctr->n_manifolds, t);
                 const uint64_t room = (uint64_t)bb < max_manifolds ? max_manifolds - bb : 0;
                 const uint32_t stored = (uint64_t)t <= room ? t : (uint32_t)room;
-                if (stored) atomicAdd(&ctr->n_uncolored, stored);
                 if (stored != t) atomicOr(&ctr->overflow, 2u);
                 atomicAdd(&ctr->n_contacts, tp);
                 if (tg) atomicAdd(&ctr->n_ground_manifolds, tg);
@@ -94,6 +95,7 @@ __global__ __launch_bounds__(kNpThreads) void k_narrowphase(
             block_base = bb;
         }
         __syncthreads();
+        bool uncolored = false;
         if (has) {
             uint32_t woff = 0;
             for (int k = 0; k < wave; ++k) woff += wcount[k];
@@ -102,19 +104,45 @@ __global__ __launch_bounds__(kNpThreads) void k_narrowphase(
                 man_a[slot] = a;
                 man_b[slot] = b;
                 man_count[slot] = (uint32_t)m.count;
-                man_color[slot] = kUncolored;
                 const unsigned long long prio = color_priority(a, b);
                 man_prio[slot] = prio;
-                // round 0 of the colouring: per-body maximum priority (order-independent u64 max)
-                atomicMax(&top0[a], prio);
-                if (b != PHYS_GROUND_ID) atomicMax(&top0[b], prio);
+                // persistent colouring (contact_solve.h): a manifold that existed in the previous update keeps
+                // its colour - exact 64-bit key match in the hash table built at the end of that update
+                uint32_t col = kUncolored;
+                if (cache_mask) {
+                    const unsigned long long key = ((unsigned long long)a << 32) | b;
+                    uint32_t h = (uint32_t)(prio >> 20) & cache_mask;
+                    for (;;) {
+                        const unsigned long long kk = cache_keys[h];
+                        if (kk == key) { col = cache_cols[h]; break; }
+                        if (kk == ~0ull) break;  // empty slot: not in the previous update
+                        h = (h + 1) & cache_mask;
+                    }
+                }
+                man_color[slot] = col;
+                if (col != kUncolored) {
+                    atomicOr(&used[a], 1ull << col);  // order-independent
+                    if (b != PHYS_GROUND_ID) atomicOr(&used[b], 1ull << col);
+                } else {
+                    uncolored = true;
+                    // round 0 of the colouring: per-body maximum priority (order-independent u64 max)
+                    atomicMax(&top0[a], prio);
+                    if (b != PHYS_GROUND_ID) atomicMax(&top0[b], prio);
+                }
                 st3(man_normal, (uint32_t)slot, m.normal);
                 float4* o = reinterpret_cast<float4*>(man_points) + 4 * slot;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) o[k] = make_float4(m.pt[k].x, m.pt[k].y, m.pt[k].z, m.depth[k]);
             }
         }
+        const unsigned long long umask = __ballot(uncolored);
+        if (lane == 0) wunc[wave] = (uint32_t)__popcll(umask);
         __syncthreads();  // wcount / block_base are reused by the next trip
+        if (threadIdx.x == 0) {
+            uint32_t t = 0;
+            for (int k = 0; k < kNpThreads / 64; ++k) t += wunc[k];
+            if (t) atomicAdd(&ctr->n_uncolored, t);  // wunc is rewritten only after two more barriers
+        }
     }
 }
 
@@ -266,6 +294,39 @@ __global__ __launch_bounds__(kColorThreads) void k_color_finish(uint32_t round, 
     }
 }
 
+// hash table (a << 32 | b) -> colour of this update's manifolds, looked up by the next update's narrow phase.
+// Open addressing, linear probing; the table has at least 1.5 slots per manifold SLOT of the world, so an
+// insert always finds room. The layout depends on arrival order, the answers (exact key matches) do not.
+__global__ __launch_bounds__(256) void k_color_table_build(uint64_t max_manifolds, const uint32_t* __restrict__ man_a,
+                                                           const uint32_t* __restrict__ man_b,
+                                                           const uint32_t* __restrict__ man_color,
+                                                           const uint64_t* __restrict__ man_prio,
+                                                           unsigned long long* __restrict__ keys,
+                                                           uint32_t* __restrict__ cols, uint32_t mask,
+                                                           uint32_t* __restrict__ slots /* [0] = count, then the slots */,
+                                                           const StepCounters* __restrict__ ctr) {
+    const uint32_t M = stored_manifolds(ctr, max_manifolds);
+    if (blockIdx.x == 0 && threadIdx.x == 0) slots[0] = M;
+    for (uint32_t m = blockIdx.x * blockDim.x + threadIdx.x; m < M; m += gridDim.x * blockDim.x) {
+        const unsigned long long key = ((unsigned long long)man_a[m] << 32) | man_b[m];
+        uint32_t h = (uint32_t)(man_prio[m] >> 20) & mask;
+        for (;;) {
+            const unsigned long long prev = atomicCAS(&keys[h], ~0ull, key);
+            if (prev == ~0ull || prev == key) { cols[h] = man_color[m]; slots[1 + m] = h; break; }
+            h = (h + 1) & mask;
+        }
+    }
+}
+
+// empties a colour table by revisiting exactly the slots its last build filled (far fewer bytes than a memset
+// of the whole table, which is sized for the world's manifold CAPACITY)
+__global__ __launch_bounds__(256) void k_color_table_clear(unsigned long long* __restrict__ keys,
+                                                           const uint32_t* __restrict__ slots) {
+    const uint32_t count = slots[0];
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x)
+        keys[slots[1 + i]] = ~0ull;
+}
+
 // ---- colour-major renumbering: counting sort of the manifolds by colour ---------------------------
 // hist (per-workgroup colour histogram) -> offsets (one workgroup scans colour-major) -> place.
 // No global atomics; the order inside a colour is (workgroup, arrival), which nothing depends on.
@@ -369,6 +430,9 @@ void launch_narrowphase(phys_world* w) {
     // colouring state of the step: used masks + three rotating priority buffers (one memset); the narrow
     // phase publishes round 0's per-body maxima as it emits manifolds
     { PHYS_PROF(w, PHYS_STAGE_COLOR); (void)hipMemsetAsync(w->color_state.p, 0, (size_t)4 * n * 8, w->stream); }
+    // persistent colouring: table of the previous update, unless this is a re-compaction update
+    const uint32_t prev_tab = (uint32_t)((w->color_epoch + 1) & 1);
+    const uint32_t cache_mask = (w->color_epoch % PHYS_COLOR_CACHE_PERIOD) != 0 && w->ctab_valid ? w->ctab_mask : 0u;
     PHYS_PROF(w, PHYS_STAGE_NARROW);
 #define PHYS_NP_LAUNCH(T)                                                                                              \
     do {                                                                                                               \
@@ -377,8 +441,9 @@ void launch_narrowphase(phys_world* w) {
         hipLaunchKernelGGL((k_narrowphase<T>), dim3((unsigned)blocks), dim3(T), 0, w->stream, n_ground, w->pairs.p,    \
                            w->max_pairs, w->pos.p, w->rot.p, w->half_extent.p, w->shape.p, w->cfg.contact_margin,      \
                            w->cfg.ground_height, w->max_manifolds, w->man_a.p, w->man_b.p, w->man_count.p,             \
-                           w->man_color.p, w->man_normal.p, w->man_points.p, w->man_prio.p, w->color_state.p + n,      \
-                           w->counters.p);                                                                             \
+                           w->man_color.p, w->man_normal.p, w->man_points.p, w->man_prio.p, w->color_state.p,          \
+                           w->color_state.p + n, (const unsigned long long*)w->ctab_keys[prev_tab].p,                  \
+                           w->ctab_cols[prev_tab].p, cache_mask, w->counters.p);                                       \
     } while (0)
     if (n <= 200000u) PHYS_NP_LAUNCH(128); else PHYS_NP_LAUNCH(256);
 #undef PHYS_NP_LAUNCH
@@ -434,6 +499,26 @@ void launch_coloring(phys_world* w) {
     { PHYS_PROF(w, PHYS_STAGE_ROWS); hipLaunchKernelGGL(k_color_hist, dim3(nb), dim3(1024), 0, s, w->max_manifolds, w->man_color.p, w->color_block_hist.p, nb, w->counters.p); }
     { PHYS_PROF(w, PHYS_STAGE_ROWS); hipLaunchKernelGGL(k_color_offsets, dim3(1), dim3(1024), 0, s, w->color_block_hist.p, nb, w->counters.p); }
     { PHYS_PROF(w, PHYS_STAGE_ROWS); hipLaunchKernelGGL(k_color_place, dim3(nb), dim3(1024), 0, s, w->max_manifolds, w->man_color.p, w->color_block_hist.p, nb, w->row_src.p, w->counters.p); }
+    {
+        // colour table of this update for the next one (the slot it overwrites was read two updates ago)
+        const uint32_t tab = (uint32_t)(w->color_epoch & 1);
+        uint64_t tb64 = ((w->hint.valid ? (uint64_t)w->hint.n_manifolds * 5 / 4 : w->max_manifolds) + 255) / 256 + 1;
+        if (tb64 > 2048) tb64 = 2048;
+        if (w->ctab_fresh[tab]) {
+            PHYS_PROF(w, PHYS_STAGE_ROWS);
+            hipLaunchKernelGGL(k_color_table_clear, dim3((unsigned)tb64), dim3(256), 0, s, (unsigned long long*)w->ctab_keys[tab].p, w->ctab_slots[tab].p);
+        } else {
+            PHYS_PROF(w, PHYS_STAGE_ROWS);
+            (void)hipMemsetAsync(w->ctab_keys[tab].p, 0xFF, ((size_t)w->ctab_mask + 1) * 8, s);  // first use of this table
+            w->ctab_fresh[tab] = true;
+        }
+        PHYS_PROF(w, PHYS_STAGE_ROWS);
+        hipLaunchKernelGGL(k_color_table_build, dim3((unsigned)tb64), dim3(256), 0, s, w->max_manifolds, w->man_a.p, w->man_b.p,
+                           w->man_color.p, w->man_prio.p, (unsigned long long*)w->ctab_keys[tab].p, w->ctab_cols[tab].p, w->ctab_mask,
+                           w->ctab_slots[tab].p, w->counters.p);
+        w->ctab_valid = true;
+        w->color_epoch++;
+    }
     if (!w->hint.valid) {
         // ... and adopts the exact counters as the first hint (the solver launches right after use them)
         (void)hipMemcpyAsync(w->h_counters, w->counters.p, sizeof(StepCounters), hipMemcpyDeviceToHost, s);

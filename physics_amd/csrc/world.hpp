@@ -173,6 +173,14 @@ struct phys_world {
     phys::DevBuf<float> man_normal;      // 3 per manifold
     phys::DevBuf<float> man_points;      // 16 per manifold: 4 x (xyz, depth)
     phys::DevBuf<uint64_t> man_prio;
+    // persistent colouring: two hash tables (this update's / the previous update's), key -> colour
+    phys::DevBuf<uint64_t> ctab_keys[2];
+    phys::DevBuf<uint32_t> ctab_cols[2];
+    phys::DevBuf<uint32_t> ctab_slots[2];  // [0] = entries of the last build, then their slot numbers (sparse clear)
+    bool ctab_fresh[2] = {false, false};  // the table has been memset once and is maintained by sparse clears
+    uint32_t ctab_mask = 0;     // capacity - 1 (power of two >= 1.5 * max_manifolds)
+    bool ctab_valid = false;    // a table of the previous update exists
+    uint64_t color_epoch = 0;   // updates with collisions since phys_set_bodies
     phys::DevBuf<uint32_t> color_block_hist;  // [colour][workgroup] histogram / offsets of the colour sort
     // colouring state
     phys::DevBuf<unsigned long long> color_state;  // 4n: used masks | three rotating per-body priority buffers
