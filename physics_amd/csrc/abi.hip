@@ -34,6 +34,7 @@ void snapshot_counters_async(phys_world* w) {
     (void)hipMemcpyAsync(w->h_snap[k], w->counters.p, sizeof(StepCounters), hipMemcpyDeviceToHost, w->stream);
     (void)hipEventRecord(w->snap_event[k], w->stream);
     w->snap_pending[k] = true;
+    w->snap_full[k] = w->snap_tag_full;  // was this update a full re-colouring?
     w->snap_next = (k + 1) % phys_world::kSnapRing;
 }
 
@@ -49,7 +50,16 @@ void poll_snapshots(phys_world* w) {
         w->hint.valid = true;
         w->hint.n_manifolds = c.n_manifolds;
         w->hint.n_colors = c.n_colors;
-        w->hint.color_rounds = c.color_rounds;
+        // colouring rounds: a full re-colouring and an incremental update need very different counts, and the
+        // incremental count fluctuates: remember the full count, and the maximum of the recent incremental ones
+        if (w->snap_full[k]) {
+            w->hint.full_rounds = c.color_rounds;
+        } else {
+            w->hint.recent_rounds[w->hint.recent_pos++ % 8] = c.color_rounds;
+            uint32_t mx = 0;
+            for (int q = 0; q < 8; ++q) mx = w->hint.recent_rounds[q] > mx ? w->hint.recent_rounds[q] : mx;
+            w->hint.color_rounds = mx;
+        }
         for (int q = 0; q < kMaxColors; ++q) w->hint.color_count[q] = c.color_count[q];
     }
 }

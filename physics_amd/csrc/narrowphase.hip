@@ -474,8 +474,13 @@ void launch_coloring(phys_world* w) {
     }
     const unsigned blocks = (unsigned)blocks64;
     uint32_t rounds = 0;
-    if (w->hint.valid) {
-        rounds = w->hint.color_rounds + 1;  // k_color_finish covers a miss
+    // a full re-colouring (every PHYS_COLOR_CACHE_PERIOD-th update) needs far more rounds than an incremental one
+    const bool full = ((w->color_epoch % PHYS_COLOR_CACHE_PERIOD) == 0) || !w->ctab_valid;
+    w->snap_tag_full = full;
+    const bool known = w->hint.valid && (!full || w->hint.full_rounds > 0);
+    if (known) {
+        const uint32_t base = full ? w->hint.full_rounds : w->hint.color_rounds;
+        rounds = base + 2 + base / 4;  // surplus launches exit at once; k_color_finish covers a miss
         for (uint32_t r = 0; r < rounds; ++r) launch_color_round(w, r, blocks);
     } else {
         // first step after phys_set_bodies: nothing is known about the scene yet, so this one step asks the
@@ -519,7 +524,7 @@ void launch_coloring(phys_world* w) {
         w->ctab_valid = true;
         w->color_epoch++;
     }
-    if (!w->hint.valid) {
+    if (!known) {
         // ... and adopts the exact counters as the first hint (the solver launches right after use them)
         (void)hipMemcpyAsync(w->h_counters, w->counters.p, sizeof(StepCounters), hipMemcpyDeviceToHost, s);
         (void)hipStreamSynchronize(s);
@@ -528,7 +533,7 @@ void launch_coloring(phys_world* w) {
             w->hint.valid = true;
             w->hint.n_manifolds = c.n_manifolds;
             w->hint.n_colors = c.n_colors;
-            w->hint.color_rounds = c.color_rounds;
+            if (full) w->hint.full_rounds = c.color_rounds; else w->hint.color_rounds = c.color_rounds;
             for (int q = 0; q < kMaxColors; ++q) w->hint.color_count[q] = c.color_count[q];
         }
     } else {

@@ -115,7 +115,11 @@ struct ProfScope {
 // correctness
 struct StepHint {
     bool valid = false;
-    uint32_t n_manifolds = 0, n_colors = 0, color_rounds = 0;
+    uint32_t n_manifolds = 0, n_colors = 0;
+    uint32_t color_rounds = 0;     // max over the recent INCREMENTAL updates
+    uint32_t full_rounds = 0;      // rounds of the last full re-colouring (0 = unknown)
+    uint32_t recent_rounds[8] = {};
+    uint32_t recent_pos = 0;
     uint32_t color_count[kMaxColors] = {};
 };
 
@@ -198,6 +202,8 @@ struct phys_world {
     phys::StepCounters* h_snap[kSnapRing] = {};  // pinned snapshots of the counters
     hipEvent_t snap_event[kSnapRing] = {};
     bool snap_pending[kSnapRing] = {};
+    bool snap_full[kSnapRing] = {};
+    bool snap_tag_full = false;
     uint32_t snap_next = 0;
     phys::Profiler prof;
     phys_stats stats{};
