@@ -190,6 +190,7 @@ int32_t phys_set_bodies(phys_world* w, uint64_t n, const float* pos, const float
     std::vector<uint32_t> h_shape(n, PHYS_SHAPE_NONE), h_gid(n);
     w->singular_inertia = false;
     w->all_diag_inertia = true;
+    w->uniform_inertia = true;
     for (uint64_t i = 0; i < n; ++i) {
         if (rot) std::memcpy(&h_rot[4 * i], rot + 4 * i, 16);
         else { h_rot[4 * i] = 0.0f; h_rot[4 * i + 1] = 0.0f; h_rot[4 * i + 2] = 0.0f; h_rot[4 * i + 3] = 1.0f; }
@@ -210,6 +211,7 @@ int32_t phys_set_bodies(phys_world* w, uint64_t n, const float* pos, const float
             if (k % 4 != 0 && inv.m[k] != 0.0f) w->all_diag_inertia = false;
         }
         h_diag[4 * i] = inv.m[0]; h_diag[4 * i + 1] = inv.m[4]; h_diag[4 * i + 2] = inv.m[8];
+        if (h_diag[4 * i] != h_diag[0] || h_diag[4 * i + 1] != h_diag[1] || h_diag[4 * i + 2] != h_diag[2]) w->uniform_inertia = false;
         if (shape_type) h_shape[i] = shape_type[i];
         if (half_extent) std::memcpy(&h_he[3 * i], half_extent + 3 * i, 12);
         h_gid[i] = (uint32_t)i;
@@ -225,6 +227,7 @@ int32_t phys_set_bodies(phys_world* w, uint64_t n, const float* pos, const float
     PHYS_HIP_TRY(hipMemcpyAsync(w->half_extent.p, h_he.data(), 12 * n, hipMemcpyHostToDevice, s));
     PHYS_HIP_TRY(hipMemcpyAsync(w->shape.p, h_shape.data(), 4 * n, hipMemcpyHostToDevice, s));
     PHYS_HIP_TRY(hipMemcpyAsync(w->global_id.p, h_gid.data(), 4 * n, hipMemcpyHostToDevice, s));
+    if (!w->all_diag_inertia) w->uniform_inertia = false;
     PHYS_HIP_TRY(hipStreamSynchronize(s));  // staging vectors die here
     if (w->cfg.flags & PHYS_FLAG_COLLISIONS) {
         const int32_t rc = collision_alloc(w);

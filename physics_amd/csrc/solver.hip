@@ -107,6 +107,7 @@ __device__ __forceinline__ void solve_row(uint32_t d, uint64_t cap, float fricti
                                           const uint32_t* __restrict__ row_b, const uint32_t* __restrict__ row_count,
                                           const float* __restrict__ row_normal, const float* __restrict__ row_data,
                                           float* __restrict__ row_acc, const float* __restrict__ inv_inertia,
+                                          uint32_t inertia_stride /* 0: one tensor shared by every body */,
                                           float* __restrict__ vel) {
     const uint32_t a = row_a[d], b = row_b[d];
     solver_manifold_t sm;
@@ -131,7 +132,7 @@ __device__ __forceinline__ void solve_row(uint32_t d, uint64_t cap, float fricti
             c.pn = 0.0f; c.pt[0] = 0.0f; c.pt[1] = 0.0f;
         }
     }
-    const m33 IA = ld_inertia<DIAG>(inv_inertia, a);
+    const m33 IA = ld_inertia<DIAG>(inv_inertia, a * inertia_stride);
     BodyVel A = ld_vel(vel, a);
     const float ima = A.inv_mass;
     v3 vA = A.v, wA = A.w;
@@ -141,7 +142,7 @@ __device__ __forceinline__ void solve_row(uint32_t d, uint64_t cap, float fricti
     float imb = 0.0f;
     v3 vB = v3_make(0.0f, 0.0f, 0.0f), wB = v3_make(0.0f, 0.0f, 0.0f);
     BodyVel B = A;
-    if (sm.has_b) { IB = ld_inertia<DIAG>(inv_inertia, b); B = ld_vel(vel, b); imb = B.inv_mass; vB = B.v; wB = B.w; }
+    if (sm.has_b) { IB = ld_inertia<DIAG>(inv_inertia, b * inertia_stride); B = ld_vel(vel, b); imb = B.inv_mass; vB = B.v; wB = B.w; }
     solve_manifold(&sm, friction, ima, &IA, imb, &IB, &vA, &wA, &vB, &wB);
     A.v = vA; A.w = wA;
     st_vel(vel, a, A);
@@ -163,11 +164,11 @@ __global__ __launch_bounds__(256) void k_solve_color(const StepCounters* __restr
                                                      const uint32_t* __restrict__ row_count,
                                                      const float* __restrict__ row_normal,
                                                      const float* __restrict__ row_data, float* __restrict__ row_acc,
-                                                     const float* __restrict__ inv_inertia, float* __restrict__ vel) {
+                                                     const float* __restrict__ inv_inertia, uint32_t inertia_stride, float* __restrict__ vel) {
     if (ctr->overflow) return;
     const uint32_t start = ctr->color_start[col], end = ctr->color_start[col + 1];
     for (uint32_t d = start + blockIdx.x * blockDim.x + threadIdx.x; d < end; d += gridDim.x * blockDim.x)
-        solve_row<DIAG>(d, cap, friction, row_a, row_b, row_count, row_normal, row_data, row_acc, inv_inertia, vel);
+        solve_row<DIAG>(d, cap, friction, row_a, row_b, row_count, row_normal, row_data, row_acc, inv_inertia, inertia_stride, vel);
 }
 
 // The colour classes [first, n_colours) of one iteration in ONE launch of ONE workgroup: colours in
@@ -183,13 +184,13 @@ __global__ __launch_bounds__(kTailThreads) void k_solve_tail(const StepCounters*
                                                             const uint32_t* __restrict__ row_count,
                                                             const float* __restrict__ row_normal,
                                                             const float* __restrict__ row_data, float* __restrict__ row_acc,
-                                                            const float* __restrict__ inv_inertia, float* __restrict__ vel) {
+                                                            const float* __restrict__ inv_inertia, uint32_t inertia_stride, float* __restrict__ vel) {
     if (ctr->overflow) return;
     const uint32_t last = ctr->n_colors;
     for (uint32_t col = first; col < last; ++col) {
         const uint32_t start = ctr->color_start[col], end = ctr->color_start[col + 1];
         for (uint32_t d = start + threadIdx.x; d < end; d += kTailThreads)
-            solve_row<DIAG>(d, cap, friction, row_a, row_b, row_count, row_normal, row_data, row_acc, inv_inertia, vel);
+            solve_row<DIAG>(d, cap, friction, row_a, row_b, row_count, row_normal, row_data, row_acc, inv_inertia, inertia_stride, vel);
         __threadfence_block();
         __syncthreads();
     }
@@ -210,6 +211,8 @@ void launch_solver(phys_world* w, float dt) {
     const uint64_t cap = w->max_manifolds;
     const dim3 tb(256);
     const bool diag = w->all_diag_inertia;
+    // every body shares one diagonal tensor (the reference's only case, identity): all lanes read entry 0
+    const uint32_t istride = w->uniform_inertia ? 0u : 1u;
     auto grid_for_count = [&](uint64_t count) {
         uint64_t b = (count * 5 / 4 + 255) / 256 + 1;
         const uint64_t hi = (cap + 255) / 256;
@@ -235,21 +238,21 @@ void launch_solver(phys_world* w, float dt) {
             if (diag)
                 hipLaunchKernelGGL(k_solve_color<true>, grid_for_count(h.color_count[col]), tb, 0, s, w->counters.p, col, cap, sp.friction,
                                    w->row_a.p, w->row_b.p, w->row_count.p, w->row_normal.p, w->row_data.p, w->row_acc.p,
-                                   w->inv_inertia_diag.p, w->vel.p);
+                                   w->inv_inertia_diag.p, istride, w->vel.p);
             else
                 hipLaunchKernelGGL(k_solve_color<false>, grid_for_count(h.color_count[col]), tb, 0, s, w->counters.p, col, cap, sp.friction,
                                    w->row_a.p, w->row_b.p, w->row_count.p, w->row_normal.p, w->row_data.p, w->row_acc.p,
-                                   w->inv_inertia.p, w->vel.p);
+                                   w->inv_inertia.p, 1u, w->vel.p);
         }
         PHYS_PROF(w, PHYS_STAGE_SOLVE_TAIL);
         if (diag)
             hipLaunchKernelGGL(k_solve_tail<true>, dim3(1), dim3(kTailThreads), 0, s, w->counters.p, big, cap, sp.friction,
                                w->row_a.p, w->row_b.p, w->row_count.p, w->row_normal.p, w->row_data.p, w->row_acc.p,
-                               w->inv_inertia_diag.p, w->vel.p);
+                               w->inv_inertia_diag.p, istride, w->vel.p);
         else
             hipLaunchKernelGGL(k_solve_tail<false>, dim3(1), dim3(kTailThreads), 0, s, w->counters.p, big, cap, sp.friction,
                                w->row_a.p, w->row_b.p, w->row_count.p, w->row_normal.p, w->row_data.p, w->row_acc.p,
-                               w->inv_inertia.p, w->vel.p);
+                               w->inv_inertia.p, 1u, w->vel.p);
     }
 }
 

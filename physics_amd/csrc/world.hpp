@@ -140,6 +140,7 @@ struct phys_world {
     bool forces_dirty = false;      // force / torque arrays hold non-zero accumulators
     bool singular_inertia = false;  // some body's inertia tensor has det == 0 (reference panics in step)
     bool all_diag_inertia = true;
+    bool uniform_inertia = true;  // all diagonal AND identical for every body
     bool aabbs_valid = false;
     bool grid_valid = false;  // bucket grid + AABBs of the last broad phase are on the device (halo entry points)
 
