@@ -145,12 +145,12 @@ int32_t phys_destroy(phys_world* w) {
                            &w->cg_rhs, &w->cg_c, &w->cg_scratch, &w->man_normal, &w->man_points, &w->row_normal,
                            &w->row_data, &w->row_acc, &w->sorted_box};
     for (auto* b : fb) b->free();
-    DevBuf<uint32_t>* ub[] = {&w->shape, &w->global_id, &w->cg_status, &w->cell_xyz, &w->bucket_of, &w->bucket_count,
+    DevBuf<uint32_t>* ub[] = {&w->shape, &w->global_id, &w->cg_status, &w->bucket_of, &w->bucket_count,
                               &w->bucket_start, &w->bucket_cursor, &w->sorted_ids, &w->scan_block_sums, &w->pairs,
                               &w->man_a, &w->man_b, &w->man_count, &w->man_color, &w->row_a, &w->row_b, &w->row_count,
-                              &w->row_src, &w->cross_pairs, &w->man_slot, &w->color_block_hist, &w->cg_cols};
+                              &w->row_src, &w->cross_pairs, &w->color_block_hist, &w->cg_cols};
     for (auto* b : ub) b->free();
-    w->pair_keys.free(); w->man_prio.free(); w->color_state.free();
+    w->man_prio.free(); w->color_state.free();
     w->d_constraints.free(); w->counters.free();
     for (int t = 0; t < 2; ++t) { w->ctab_keys[t].free(); w->ctab_cols[t].free(); w->ctab_slots[t].free(); }
     w->prof.destroy();

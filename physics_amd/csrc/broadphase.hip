@@ -142,27 +142,6 @@ __global__ __launch_bounds__(kScanThreads) void k_scan_final(const uint32_t* __r
     }
 }
 
-// small tables: the whole exclusive scan in ONE workgroup (one launch instead of three). Each thread owns
-// one contiguous segment of count/1024 buckets; one barrier.
-__global__ __launch_bounds__(1024) void k_scan_single(const uint32_t* __restrict__ in, uint32_t count,
-                                                      uint32_t* __restrict__ out /*count + 1*/) {
-    __shared__ uint32_t wtot[16];
-    const uint32_t seg = (count + 1023) / 1024;
-    const uint32_t base = threadIdx.x * seg;
-    uint32_t s = 0;
-    for (uint32_t k = 0; k < seg; ++k) s += (base + k < count) ? in[base + k] : 0u;
-    const uint32_t inc = wave_inclusive_scan(s);
-    if ((threadIdx.x & 63) == 63) wtot[threadIdx.x >> 6] = inc;
-    __syncthreads();
-    uint32_t off = 0;
-    for (uint32_t k = 0; k < (threadIdx.x >> 6); ++k) off += wtot[k];
-    uint32_t run = off + inc - s;
-    for (uint32_t k = 0; k < seg; ++k) {
-        if (base + k < count) { out[base + k] = run; run += in[base + k]; }
-    }
-    if (threadIdx.x == 1023) out[count] = run;
-}
-
 // ---- group bodies by bucket -----------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_scatter(uint32_t n, const float* __restrict__ aabb,
                                                  const uint32_t* __restrict__ bucket_of,
@@ -321,13 +300,12 @@ int32_t collision_alloc(phys_world* w) {
     PHYS_HIP_TRY(w->bucket_start.resize((size_t)T + 1));
     PHYS_HIP_TRY(w->scan_block_sums.resize((T + kScanChunk - 1) / kScanChunk + 1));
     PHYS_HIP_TRY(w->sorted_ids.resize(n));
-    PHYS_HIP_TRY(w->cell_xyz.resize(0));
     PHYS_HIP_TRY(w->sorted_box.resize(6 * n));
     PHYS_HIP_TRY(w->pairs.resize(2 * w->max_pairs));
     if (!(w->cfg.flags & PHYS_FLAG_BROADPHASE_ONLY)) {
         const uint64_t M = w->max_manifolds;
         PHYS_HIP_TRY(w->man_a.resize(M)); PHYS_HIP_TRY(w->man_b.resize(M)); PHYS_HIP_TRY(w->man_count.resize(M));
-        PHYS_HIP_TRY(w->man_color.resize(M)); PHYS_HIP_TRY(w->man_slot.resize(M));
+        PHYS_HIP_TRY(w->man_color.resize(M));
         PHYS_HIP_TRY(w->man_normal.resize(3 * M)); PHYS_HIP_TRY(w->man_points.resize(16 * M));
         PHYS_HIP_TRY(w->man_prio.resize(M));
         PHYS_HIP_TRY(w->color_state.resize(4 * n));
@@ -362,10 +340,7 @@ void launch_broadphase(phys_world* w) {
     { PHYS_PROF(w, PHYS_STAGE_GRID); (void)hipMemsetAsync(w->bucket_count.p, 0, (size_t)T * 4, s); }
     { PHYS_PROF(w, PHYS_STAGE_GRID); hipLaunchKernelGGL(k_cell_assign, gb, tb, 0, s, n, w->aabb.p, w->shape.p, w->counters.p, axis_mask, w->bucket_of.p,
                        w->bucket_cursor.p, w->bucket_count.p); }
-    if (T <= 1024u) {  // (measured: for T >= 32k the three-kernel scan is faster than one workgroup)
-        PHYS_PROF(w, PHYS_STAGE_GRID);
-        hipLaunchKernelGGL(k_scan_single, dim3(1), dim3(1024), 0, s, w->bucket_count.p, T, w->bucket_start.p);
-    } else {
+    {
         const uint32_t nblk = (T + kScanChunk - 1) / kScanChunk;
         { PHYS_PROF(w, PHYS_STAGE_GRID); hipLaunchKernelGGL(k_scan_reduce, dim3(nblk), dim3(kScanThreads), 0, s, w->bucket_count.p, T, w->scan_block_sums.p); }
         { PHYS_PROF(w, PHYS_STAGE_GRID); hipLaunchKernelGGL(k_scan_block_sums, dim3(1), dim3(1024), 0, s, w->scan_block_sums.p, nblk); }

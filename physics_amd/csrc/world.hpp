@@ -64,7 +64,6 @@ struct StepCounters {
     uint32_t n_ground_manifolds;
     uint32_t color_count[kMaxColors];  // manifolds per colour
     uint32_t color_start[kMaxColors + 1];
-    uint32_t color_cursor[kMaxColors];
     // LAST member: survives the per-step reset (only the bytes before it are zeroed), so a wave issues the
     // same-address atomicMax only when it RAISES the bound. It is a running upper bound of the largest
     // fattened-AABB edge (float bits; positive floats order as uints), re-derived from zero every 32 steps.
@@ -165,16 +164,14 @@ struct phys_world {
     uint64_t max_pairs = 0, max_manifolds = 0;
     uint32_t grid_table_size = 0;  // hashed-grid buckets (power of two)
     phys::DevBuf<phys::StepCounters> counters;
-    phys::DevBuf<uint32_t> cell_xyz;     // 3n: integer cell coordinates of every body
     phys::DevBuf<uint32_t> bucket_of;    // n
     phys::DevBuf<uint32_t> bucket_count, bucket_start, bucket_cursor;  // table
     phys::DevBuf<uint32_t> sorted_ids;   // n: body ids grouped by bucket
     phys::DevBuf<float> sorted_box;      // 6n: AABBs in bucket order (streamed by the pair kernel)
     phys::DevBuf<uint32_t> scan_block_sums;
     phys::DevBuf<uint32_t> pairs;        // 2 * max_pairs
-    phys::DevBuf<uint64_t> pair_keys;    // sort scratch for phys_broadphase
     // manifolds, geometry stage (storage order = emission order, arbitrary)
-    phys::DevBuf<uint32_t> man_a, man_b, man_count, man_color, man_slot;
+    phys::DevBuf<uint32_t> man_a, man_b, man_count, man_color;
     phys::DevBuf<float> man_normal;      // 3 per manifold
     phys::DevBuf<float> man_points;      // 16 per manifold: 4 x (xyz, depth)
     phys::DevBuf<uint64_t> man_prio;

@@ -58,3 +58,38 @@ def test_pub_field_edits_between_frames_reach_the_device():
     # set_bodies resets previous_solution (the mirror re-uploads on an edit, as documented), so this matches
     assert np.allclose(np.float32(r["after_edit_pos"]), o2.get_transforms()[0][0], rtol=0, atol=0)
     assert len(lam) == 6
+
+
+def test_python_mirror_reads_like_the_reference_demo():
+    """src/lib.rs:20-42 + the frame loop of :55-59 written against physics_amd.state."""
+    import datetime
+    from physics_amd.state import (ConstraintSolver, Entity, FixedOrientationConstraint, FixToPointConstraint,
+                                   PhysicsState, RigidBody)
+    from oracle import binding as ob
+    g = GOLD["G1"]
+    rigid_body = RigidBody.new(0)
+    rigid_body.position = np.array([1.0, 0.0, 0.0], np.float32)
+    rigid_body.rotation = ob.quat_from_euler(1.0, 0.0, 0.0, ob.TRIG_DET)  # UnitQuaternion::from_euler_angles
+    physics_state = PhysicsState(
+        entities=[Entity(rigid_body, 0)],
+        constraint_solver=ConstraintSolver([FixToPointConstraint(rigid_body.index, [0, 0, 0]),
+                                            FixedOrientationConstraint(rigid_body.index, [0, 0, 0])]))
+    physics_state.update(datetime.timedelta(microseconds=16666) + datetime.timedelta(microseconds=0))  # ~1/60 s
+    physics_state = PhysicsState(entities=[Entity(rigid_body, 0)], constraint_solver=physics_state.constraint_solver)
+    rigid_body.position = np.array([1.0, 0.0, 0.0], np.float32)
+    rigid_body.rotation = ob.quat_from_euler(1.0, 0.0, 0.0, ob.TRIG_DET)
+    rigid_body.lin_velocity[:] = 0
+    rigid_body.angular_velocity[:] = 0
+    physics_state.update(g["dt_nanos"])
+    b = physics_state.entities[0].body
+    assert np.array_equal(b.position, np.float32(g["pos"])) and np.array_equal(b.rotation, np.float32(g["rot_ijkw"]))
+    assert np.array_equal(physics_state.previous_solution, np.float32(g["lambda"]))
+    assert not b.force.any() and not b.torque.any()
+    # pub-field edit + force between frames, then apply_gravity / step as separate calls
+    b.apply_force_at_offset([0, 1, 0], [1, 0, 0])
+    physics_state.apply_gravity()
+    assert np.allclose(physics_state.entities[0].body.force, [0, -8.81, 0], atol=1e-6)
+    physics_state.step(g["dt_nanos"])
+    assert not physics_state.entities[0].body.force.any()
+    m = physics_state.instance_matrices()
+    assert m.shape == (1, 16) and np.array_equal(m[0, 12:15], physics_state.entities[0].body.position)
