@@ -150,7 +150,7 @@ int32_t phys_destroy(phys_world* w) {
                               &w->man_a, &w->man_b, &w->man_count, &w->man_color, &w->row_a, &w->row_b, &w->row_count,
                               &w->row_src, &w->cross_pairs, &w->color_block_hist, &w->cg_cols};
     for (auto* b : ub) b->free();
-    w->man_prio.free(); w->color_state.free();
+    w->man_prio.free(); w->color_state.free(); w->bucket_count.free(); w->step_zero.free();
     w->d_constraints.free(); w->counters.free();
     for (int t = 0; t < 2; ++t) { w->ctab_keys[t].free(); w->ctab_cols[t].free(); w->ctab_slots[t].free(); }
     w->prof.destroy();
@@ -321,11 +321,7 @@ static int32_t enqueue_update(phys_world* w, float dt) {
     if (!collisions) {
         launch_step_full(w, dt, gravity_pending);
     } else {
-        {
-            PHYS_PROF(w, PHYS_STAGE_MISC);
-            const size_t bytes = (w->steps % 32 == 0) ? sizeof(StepCounters) : kCountersStepResetBytes;
-            PHYS_HIP_TRY(hipMemsetAsync(w->counters.p, 0, bytes, w->stream));
-        }
+        zero_step_state(w, /*including_extent=*/w->steps % 32 == 0);
         launch_step_velocity_aabb(w, dt, gravity_pending);
         launch_broadphase(w);
         if (!(w->cfg.flags & PHYS_FLAG_BROADPHASE_ONLY)) {
@@ -442,7 +438,7 @@ int32_t phys_broadphase(phys_world* w, uint32_t* pairs_out, uint64_t cap, uint64
     if (!n_pairs) return fail(PHYS_ERR_INVALID_ARG, "null n_pairs");
     if (!(w->cfg.flags & PHYS_FLAG_COLLISIONS)) return fail(PHYS_ERR_UNSUPPORTED, "world created without PHYS_FLAG_COLLISIONS");
     if (w->n == 0) { *n_pairs = 0; return PHYS_OK; }
-    PHYS_HIP_TRY(hipMemsetAsync(w->counters.p, 0, sizeof(StepCounters), w->stream));
+    zero_step_state(w, true);
     launch_aabb_only(w);
     launch_broadphase(w);
     PHYS_HIP_TRY(hipGetLastError());

@@ -294,9 +294,22 @@ int32_t collision_alloc(phys_world* w) {
     }
     w->grid_table_size = table_size_for(n);
     const uint32_t T = w->grid_table_size;
+    {
+        // one allocation, zeroed by one memset per step: [bucket counts | colouring state | StepCounters]
+        const size_t b_bytes = ((size_t)T * 4 + 255) / 256 * 256;
+        const size_t c_bytes = (w->cfg.flags & PHYS_FLAG_BROADPHASE_ONLY) ? 0 : ((size_t)4 * n * 8 + 255) / 256 * 256;
+        w->counters.free(); w->bucket_count.free(); w->color_state.free();
+        w->step_zero.free();
+        PHYS_HIP_TRY(w->step_zero.resize(b_bytes + c_bytes + sizeof(StepCounters)));
+        w->bucket_count.point_at(reinterpret_cast<uint32_t*>(w->step_zero.p), T);
+        w->color_state.point_at(reinterpret_cast<unsigned long long*>(w->step_zero.p + b_bytes), c_bytes / 8);
+        w->counters.point_at(reinterpret_cast<StepCounters*>(w->step_zero.p + b_bytes + c_bytes), 1);
+        w->step_zero_reset_bytes = b_bytes + c_bytes + kCountersStepResetBytes;
+        w->step_zero_full_bytes = b_bytes + c_bytes + sizeof(StepCounters);
+        PHYS_HIP_TRY(hipMemsetAsync(w->step_zero.p, 0, w->step_zero_full_bytes, w->stream));
+    }
     PHYS_HIP_TRY(w->bucket_of.resize(n));
     PHYS_HIP_TRY(w->bucket_cursor.resize(n));  // rank of each body inside its bucket
-    PHYS_HIP_TRY(w->bucket_count.resize(T));
     PHYS_HIP_TRY(w->bucket_start.resize((size_t)T + 1));
     PHYS_HIP_TRY(w->scan_block_sums.resize((T + kScanChunk - 1) / kScanChunk + 1));
     PHYS_HIP_TRY(w->sorted_ids.resize(n));
@@ -308,7 +321,6 @@ int32_t collision_alloc(phys_world* w) {
         PHYS_HIP_TRY(w->man_color.resize(M));
         PHYS_HIP_TRY(w->man_normal.resize(3 * M)); PHYS_HIP_TRY(w->man_points.resize(16 * M));
         PHYS_HIP_TRY(w->man_prio.resize(M));
-        PHYS_HIP_TRY(w->color_state.resize(4 * n));
         PHYS_HIP_TRY(w->row_src.resize(M));
         {
             uint64_t cap = 4096;
@@ -327,6 +339,11 @@ int32_t collision_alloc(phys_world* w) {
     return PHYS_OK;
 }
 
+void zero_step_state(phys_world* w, bool including_extent) {
+    PHYS_PROF(w, PHYS_STAGE_MISC);
+    (void)hipMemsetAsync(w->step_zero.p, 0, including_extent ? w->step_zero_full_bytes : w->step_zero_reset_bytes, w->stream);
+}
+
 void launch_broadphase(phys_world* w) {
     const uint32_t n = (uint32_t)w->n;
     if (n == 0) return;
@@ -337,7 +354,6 @@ void launch_broadphase(phys_world* w) {
     const uint32_t axis_mask = (1u << bits) - 1u;
     hipStream_t s = w->stream;
     const dim3 gb((n + 255) / 256), tb(256);
-    { PHYS_PROF(w, PHYS_STAGE_GRID); (void)hipMemsetAsync(w->bucket_count.p, 0, (size_t)T * 4, s); }
     { PHYS_PROF(w, PHYS_STAGE_GRID); hipLaunchKernelGGL(k_cell_assign, gb, tb, 0, s, n, w->aabb.p, w->shape.p, w->counters.p, axis_mask, w->bucket_of.p,
                        w->bucket_cursor.p, w->bucket_count.p); }
     {

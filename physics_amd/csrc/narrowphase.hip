@@ -304,7 +304,16 @@ __global__ __launch_bounds__(256) void k_color_table_build(uint64_t max_manifold
                                                            unsigned long long* __restrict__ keys,
                                                            uint32_t* __restrict__ cols, uint32_t mask,
                                                            uint32_t* __restrict__ slots /* [0] = count, then the slots */,
+                                                           unsigned long long* __restrict__ other_keys,
+                                                           const uint32_t* __restrict__ other_slots,
                                                            const StepCounters* __restrict__ ctr) {
+    // the OTHER table (looked up by this update's narrow phase, rebuilt by the next update) is emptied here by
+    // revisiting exactly the slots its last build filled: no memset of a capacity-sized table, no extra launch
+    if (other_keys) {
+        const uint32_t count = other_slots[0];
+        for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x)
+            other_keys[other_slots[1 + i]] = ~0ull;
+    }
     const uint32_t M = stored_manifolds(ctr, max_manifolds);
     if (blockIdx.x == 0 && threadIdx.x == 0) slots[0] = M;
     for (uint32_t m = blockIdx.x * blockDim.x + threadIdx.x; m < M; m += gridDim.x * blockDim.x) {
@@ -316,15 +325,6 @@ __global__ __launch_bounds__(256) void k_color_table_build(uint64_t max_manifold
             h = (h + 1) & mask;
         }
     }
-}
-
-// empties a colour table by revisiting exactly the slots its last build filled (far fewer bytes than a memset
-// of the whole table, which is sized for the world's manifold CAPACITY)
-__global__ __launch_bounds__(256) void k_color_table_clear(unsigned long long* __restrict__ keys,
-                                                           const uint32_t* __restrict__ slots) {
-    const uint32_t count = slots[0];
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x)
-        keys[slots[1 + i]] = ~0ull;
 }
 
 // ---- colour-major renumbering: counting sort of the manifolds by colour ---------------------------
@@ -422,6 +422,47 @@ __global__ __launch_bounds__(1024) void k_color_place(uint64_t max_manifolds, co
     }
 }
 
+// small manifold counts: histogram, offsets and placement of the colour-major renumbering in ONE workgroup
+// (one launch instead of three)
+__global__ __launch_bounds__(1024) void k_color_sort_small(uint64_t max_manifolds, const uint32_t* __restrict__ man_color,
+                                                           uint32_t* __restrict__ row_src, StepCounters* __restrict__ ctr) {
+    __shared__ uint32_t h[PHYS_MAX_COLORS], cursor[PHYS_MAX_COLORS];
+    if (threadIdx.x < PHYS_MAX_COLORS) h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t M = stored_manifolds(ctr, max_manifolds);
+    for (uint32_t m = threadIdx.x; m < M; m += 1024) {
+        const uint32_t c = man_color[m];
+        if (c < (uint32_t)PHYS_MAX_COLORS) atomicAdd(&h[c], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < PHYS_MAX_COLORS) {  // one wave: exclusive scan of the 64 counts
+        const uint32_t cnt = h[threadIdx.x];
+        uint32_t inc = cnt;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t o = (uint32_t)__shfl_up((int)inc, off, 64);
+            if ((int)threadIdx.x >= off) inc += o;
+        }
+        const uint32_t start = inc - cnt;
+        cursor[threadIdx.x] = start;
+        ctr->color_start[threadIdx.x] = start;
+        ctr->color_count[threadIdx.x] = cnt;
+        if (threadIdx.x == 63) ctr->color_start[PHYS_MAX_COLORS] = inc;
+        uint32_t cmax = cnt ? threadIdx.x + 1 : 0;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const uint32_t o = (uint32_t)__shfl_xor((int)cmax, off, 64);
+            cmax = o > cmax ? o : cmax;
+        }
+        if (threadIdx.x == 0) ctr->n_colors = cmax;
+    }
+    __syncthreads();
+    for (uint32_t m = threadIdx.x; m < M; m += 1024) {
+        const uint32_t c = man_color[m];
+        if (c < (uint32_t)PHYS_MAX_COLORS) row_src[atomicAdd(&cursor[c], 1u)] = m;
+    }
+}
+
 void launch_narrowphase(phys_world* w) {
     const uint32_t n = (uint32_t)w->n;
     if (n == 0) return;
@@ -429,7 +470,6 @@ void launch_narrowphase(phys_world* w) {
     const uint64_t work = (uint64_t)n_ground + w->max_pairs;
     // colouring state of the step: used masks + three rotating priority buffers (one memset); the narrow
     // phase publishes round 0's per-body maxima as it emits manifolds
-    { PHYS_PROF(w, PHYS_STAGE_COLOR); (void)hipMemsetAsync(w->color_state.p, 0, (size_t)4 * n * 8, w->stream); }
     // persistent colouring: table of the previous update, unless this is a re-compaction update
     const uint32_t prev_tab = (uint32_t)((w->color_epoch + 1) & 1);
     const uint32_t cache_mask = (w->color_epoch % PHYS_COLOR_CACHE_PERIOD) != 0 && w->ctab_valid ? w->ctab_mask : 0u;
@@ -501,26 +541,31 @@ void launch_coloring(phys_world* w) {
         nb = 1;
         while (nb < want && nb < (uint32_t)kSortBlocksMax) nb <<= 1;
     }
-    { PHYS_PROF(w, PHYS_STAGE_ROWS); hipLaunchKernelGGL(k_color_hist, dim3(nb), dim3(1024), 0, s, w->max_manifolds, w->man_color.p, w->color_block_hist.p, nb, w->counters.p); }
-    { PHYS_PROF(w, PHYS_STAGE_ROWS); hipLaunchKernelGGL(k_color_offsets, dim3(1), dim3(1024), 0, s, w->color_block_hist.p, nb, w->counters.p); }
-    { PHYS_PROF(w, PHYS_STAGE_ROWS); hipLaunchKernelGGL(k_color_place, dim3(nb), dim3(1024), 0, s, w->max_manifolds, w->man_color.p, w->color_block_hist.p, nb, w->row_src.p, w->counters.p); }
+    if (w->hint.valid && w->hint.n_manifolds <= 24576u) {
+        PHYS_PROF(w, PHYS_STAGE_ROWS);
+        hipLaunchKernelGGL(k_color_sort_small, dim3(1), dim3(1024), 0, s, w->max_manifolds, w->man_color.p, w->row_src.p, w->counters.p);
+    } else {
+        { PHYS_PROF(w, PHYS_STAGE_ROWS); hipLaunchKernelGGL(k_color_hist, dim3(nb), dim3(1024), 0, s, w->max_manifolds, w->man_color.p, w->color_block_hist.p, nb, w->counters.p); }
+        { PHYS_PROF(w, PHYS_STAGE_ROWS); hipLaunchKernelGGL(k_color_offsets, dim3(1), dim3(1024), 0, s, w->color_block_hist.p, nb, w->counters.p); }
+        { PHYS_PROF(w, PHYS_STAGE_ROWS); hipLaunchKernelGGL(k_color_place, dim3(nb), dim3(1024), 0, s, w->max_manifolds, w->man_color.p, w->color_block_hist.p, nb, w->row_src.p, w->counters.p); }
+    }
     {
         // colour table of this update for the next one (the slot it overwrites was read two updates ago)
         const uint32_t tab = (uint32_t)(w->color_epoch & 1);
         uint64_t tb64 = ((w->hint.valid ? (uint64_t)w->hint.n_manifolds * 5 / 4 : w->max_manifolds) + 255) / 256 + 1;
         if (tb64 > 2048) tb64 = 2048;
-        if (w->ctab_fresh[tab]) {
-            PHYS_PROF(w, PHYS_STAGE_ROWS);
-            hipLaunchKernelGGL(k_color_table_clear, dim3((unsigned)tb64), dim3(256), 0, s, (unsigned long long*)w->ctab_keys[tab].p, w->ctab_slots[tab].p);
-        } else {
+        if (!w->ctab_fresh[tab]) {
             PHYS_PROF(w, PHYS_STAGE_ROWS);
             (void)hipMemsetAsync(w->ctab_keys[tab].p, 0xFF, ((size_t)w->ctab_mask + 1) * 8, s);  // first use of this table
             w->ctab_fresh[tab] = true;
         }
+        const uint32_t other = tab ^ 1u;
+        const bool clear_other = w->ctab_fresh[other];  // it holds the previous update's entries
         PHYS_PROF(w, PHYS_STAGE_ROWS);
         hipLaunchKernelGGL(k_color_table_build, dim3((unsigned)tb64), dim3(256), 0, s, w->max_manifolds, w->man_a.p, w->man_b.p,
                            w->man_color.p, w->man_prio.p, (unsigned long long*)w->ctab_keys[tab].p, w->ctab_cols[tab].p, w->ctab_mask,
-                           w->ctab_slots[tab].p, w->counters.p);
+                           w->ctab_slots[tab].p, clear_other ? (unsigned long long*)w->ctab_keys[other].p : nullptr,
+                           w->ctab_slots[other].p, w->counters.p);
         w->ctab_valid = true;
         w->color_epoch++;
     }

@@ -44,10 +44,14 @@ struct DevBuf {
         return e;
     }
     void free() {
-        if (p) (void)hipFree(p);
+        if (p && !view) (void)hipFree(p);
         p = nullptr;
         n = 0;
+        view = false;
     }
+    // non-owning window into another allocation (the per-step zeroed block)
+    bool view = false;
+    void point_at(T* ptr, size_t count) { free(); p = ptr; n = count; view = true; }
 };
 
 // device-side counters of the collision pipeline (one 256-B block, zeroed per step by one memset)
@@ -68,7 +72,7 @@ struct StepCounters {
     // same-address atomicMax only when it RAISES the bound. It is a running upper bound of the largest
     // fattened-AABB edge (float bits; positive floats order as uints), re-derived from zero every 32 steps.
     // Any upper bound is a valid grid cell size: the pair SET does not depend on it.
-    uint32_t max_extent_bits;
+    alignas(16) uint32_t max_extent_bits;
 };
 constexpr size_t kCountersStepResetBytes = offsetof(StepCounters, max_extent_bits);
 
@@ -163,6 +167,11 @@ struct phys_world {
     // collision pipeline (A10-A12)
     uint64_t max_pairs = 0, max_manifolds = 0;
     uint32_t grid_table_size = 0;  // hashed-grid buckets (power of two)
+    // counters, bucket_count and color_state are windows into ONE allocation (step_zero) laid out
+    // [bucket counts | colouring state | StepCounters], so one memset per step zeroes all three (up to, not
+    // including, StepCounters::max_extent_bits at the very end)
+    phys::DevBuf<uint8_t> step_zero;
+    size_t step_zero_reset_bytes = 0, step_zero_full_bytes = 0;
     phys::DevBuf<phys::StepCounters> counters;
     phys::DevBuf<uint32_t> bucket_of;    // n
     phys::DevBuf<uint32_t> bucket_count, bucket_start, bucket_cursor;  // table
