@@ -101,18 +101,21 @@ __device__ __forceinline__ m33 ld_inertia<true>(const float* __restrict__ p, uin
     return M;
 }
 
-// one manifold row d of the colour-major numbering: load, solve_manifold, store
-template <bool DIAG>
-__device__ __forceinline__ void solve_row(uint32_t d, uint64_t cap, float friction, const uint32_t* __restrict__ row_a,
-                                          const uint32_t* __restrict__ row_b, const uint32_t* __restrict__ row_count,
-                                          const float* __restrict__ row_normal, const float* __restrict__ row_data,
-                                          float* __restrict__ row_acc, const float* __restrict__ inv_inertia,
-                                          uint32_t inertia_stride /* 0: one tensor shared by every body */,
-                                          float* __restrict__ vel) {
-    const uint32_t a = row_a[d], b = row_b[d];
+// one manifold row d of the colour-major numbering, in registers
+struct RowRegs {
+    uint32_t a, b;
     solver_manifold_t sm;
+};
+
+// part 1: everything that does NOT depend on body velocities (can be fetched a phase ahead)
+__device__ __forceinline__ void load_row(RowRegs& R, uint32_t d, uint64_t cap, const uint32_t* __restrict__ row_a,
+                                         const uint32_t* __restrict__ row_b, const uint32_t* __restrict__ row_count,
+                                         const float* __restrict__ row_normal, const float* __restrict__ row_data,
+                                         const float* __restrict__ row_acc) {
+    R.a = row_a[d]; R.b = row_b[d];
+    solver_manifold_t& sm = R.sm;
     sm.count = (int)row_count[d];
-    sm.has_b = b != PHYS_GROUND_ID;
+    sm.has_b = R.b != PHYS_GROUND_ID;
     sm.n = v3_make(row_normal[0 * cap + d], row_normal[1 * cap + d], row_normal[2 * cap + d]);
     tangent_basis(sm.n, &sm.t1, &sm.t2);  // same inputs as solver_prep => same bits as the stored basis
 #pragma unroll
@@ -132,6 +135,16 @@ __device__ __forceinline__ void solve_row(uint32_t d, uint64_t cap, float fricti
             c.pn = 0.0f; c.pt[0] = 0.0f; c.pt[1] = 0.0f;
         }
     }
+}
+
+// part 2: gather the two bodies, solve_manifold, write velocities and accumulated impulses back
+template <bool DIAG>
+__device__ __forceinline__ void solve_loaded_row(RowRegs& R, uint32_t d, uint64_t cap, float friction,
+                                                 float* __restrict__ row_acc, const float* __restrict__ inv_inertia,
+                                                 uint32_t inertia_stride /* 0: one tensor shared by every body */,
+                                                 float* __restrict__ vel) {
+    solver_manifold_t& sm = R.sm;
+    const uint32_t a = R.a, b = R.b;
     const m33 IA = ld_inertia<DIAG>(inv_inertia, a * inertia_stride);
     BodyVel A = ld_vel(vel, a);
     const float ima = A.inv_mass;
@@ -154,6 +167,17 @@ __device__ __forceinline__ void solve_row(uint32_t d, uint64_t cap, float fricti
             acc[0 * cap] = sm.row[k].pn; acc[1 * cap] = sm.row[k].pt[0]; acc[2 * cap] = sm.row[k].pt[1];
         }
     }
+}
+
+template <bool DIAG>
+__device__ __forceinline__ void solve_row(uint32_t d, uint64_t cap, float friction, const uint32_t* __restrict__ row_a,
+                                          const uint32_t* __restrict__ row_b, const uint32_t* __restrict__ row_count,
+                                          const float* __restrict__ row_normal, const float* __restrict__ row_data,
+                                          float* __restrict__ row_acc, const float* __restrict__ inv_inertia,
+                                          uint32_t inertia_stride, float* __restrict__ vel) {
+    RowRegs R;
+    load_row(R, d, cap, row_a, row_b, row_count, row_normal, row_data, row_acc);
+    solve_loaded_row<DIAG>(R, d, cap, friction, row_acc, inv_inertia, inertia_stride, vel);
 }
 
 // one colour of one iteration; the row range comes from the device-side colour table
@@ -187,8 +211,14 @@ __global__ __launch_bounds__(kTailThreads) void k_solve_tail(const StepCounters*
                                                             const float* __restrict__ inv_inertia, uint32_t inertia_stride, float* __restrict__ vel) {
     if (ctr->overflow) return;
     const uint32_t last = ctr->n_colors;
+    if (first >= last) return;
+    // the colour table goes to LDS once: a scalar load from global memory per colour phase would put a full
+    // memory round trip in front of every phase
+    __shared__ uint32_t s_start[PHYS_MAX_COLORS + 1];
+    if (threadIdx.x <= (uint32_t)PHYS_MAX_COLORS) s_start[threadIdx.x] = ctr->color_start[threadIdx.x];
+    __syncthreads();
     for (uint32_t col = first; col < last; ++col) {
-        const uint32_t start = ctr->color_start[col], end = ctr->color_start[col + 1];
+        const uint32_t start = s_start[col], end = s_start[col + 1];
         for (uint32_t d = start + threadIdx.x; d < end; d += kTailThreads)
             solve_row<DIAG>(d, cap, friction, row_a, row_b, row_count, row_normal, row_data, row_acc, inv_inertia, inertia_stride, vel);
         __threadfence_block();
