@@ -31,7 +31,7 @@ KERNEL_OF_STAGE = {
     "step_full": "k_step_full", "velocity_aabb": "k_step_velocity_aabb", "grid": "k_cell_assign+scan+k_scatter",
     "pairs": "k_find_pairs", "narrow": "k_narrowphase", "color": "k_color_round",
     "rows": "k_rows_build+k_color_hist+k_color_offsets+k_color_place", "solve": "k_solve_color",
-    "solve_tail": "k_solve_tail", "position": "k_step_position",
+    "solve_tail": "k_solve_tail", "solve_flow": "k_solve_flow", "position": "k_step_position",
 }
 
 
@@ -55,7 +55,8 @@ def stage_bytes(stage, st, iters):
         return 28 * m  # ids + priority + colour + slot, once
     if stage == "rows":
         return 100 * m + 24 * m + 76 * k + 52 * (m + mb)
-    if stage == "solve":
+    if stage in ("solve", "solve_flow"):
+        # (k_solve_flow makes all iterations in one launch; same job, same compulsory bytes)
         # per body and iteration: v, w read 24 + written 24, inverse mass 4, inverse inertia diagonal 12
         # (all benchmark scenes have diagonal tensors; 36 with a full tensor)
         return iters * (24 * m + 64 * k + 64 * (m + mb))
@@ -202,8 +203,14 @@ def main():
     rehearsal = os.environ.get("PHYS_BENCH_REHEARSAL") == "1"
     if rehearsal:
         local_rank = 0
-    if world_size > 1:
+    # PHYS_BENCH_FORCE_DIST=1: take the sharded path (RCCL collective included) even with one rank, so the
+    # N > 1 code is exercised end to end on a one-GPU box
+    sharded = world_size > 1 or os.environ.get("PHYS_BENCH_FORCE_DIST") == "1"
+    if sharded:
         import torch.distributed as dist_mod
+        os.environ.setdefault("MASTER_PORT", "29517")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
         if rehearsal:
@@ -218,7 +225,7 @@ def main():
     default_preroll = {"c1": 100, "c2": 150, "c3": 150, "c5": 30, "t1m": 100, "c4": 0}
     preroll = args.preroll if args.preroll >= 0 else default_preroll[args.workload]
     halo = None
-    if n_gpus == 1:
+    if not sharded:
         scene = scenes.SCENES[args.workload]()
     else:
         from physics_amd import sharding
@@ -266,7 +273,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": scene.name, "n_bodies": n_total, "bodies_per_gpu": scene.n,
                        "solver_iterations": iters, "dt_nanos": DT_NANOS, "preroll_steps": preroll,
-                       "sharding": "none" if n_gpus == 1 else f"x-slabs x{n_gpus}, halo all-gather per step"},
+                       "sharding": "none" if not sharded else f"x-slabs x{n_gpus}, halo all-gather per step"},
             "steps_per_sec": round(args.steps / elapsed, 2),
             "pairs_per_sec": round(pairs_total * args.steps / elapsed, 1),
             "scene_stats": st,
@@ -278,7 +285,7 @@ def main():
         pass
     world.close()
 
-    if rank == 0 and n_gpus == 1:
+    if rank == 0 and not sharded:
         if not args.no_cpu_baseline:
             sample = 200 if args.workload in ("c1", "c2") else 10
             out["cpu_baseline"] = cpu_baseline(scene, preroll, sample)

@@ -49,6 +49,8 @@ extern "C" {
 #define PHYS_FLAG_GROUND_PLANE 0x2u   /* static plane y = ground_height, normal +y */
 #define PHYS_FLAG_EXACT_ROTATION 0x4u /* OFF (default) = reference quirk Q1: dq = exp(a*sin(th/2)/2) */
 #define PHYS_FLAG_BROADPHASE_ONLY 0x8u /* with COLLISIONS: stop after the candidate-pair list */
+#define PHYS_FLAG_SOLVER_PER_COLOR 0x10u /* contact solver as one launch per colour class instead of the single-launch
+                                            dataflow kernel; same order of updates per body, bit-identical results */
 
 typedef struct phys_config {
     uint32_t abi_version;       /* PHYS_ABI_VERSION */
@@ -173,7 +175,8 @@ int32_t phys_get_color_counts(phys_world* w, uint32_t* counts_out /*64*/);
 #define PHYS_STAGE_CONSTRAINTS 9u   /* constraint assembly + CG (A3-A7) */
 #define PHYS_STAGE_MISC 10u         /* memsets, halo */
 #define PHYS_STAGE_SOLVE_TAIL 11u   /* k_solve_tail: the small colours of one iteration in one workgroup */
-#define PHYS_STAGE_COUNT 12u
+#define PHYS_STAGE_SOLVE_FLOW 12u   /* k_solve_flow: all iterations and colours in one launch */
+#define PHYS_STAGE_COUNT 13u
 typedef struct phys_profile {
     double ms[PHYS_STAGE_COUNT];         /* summed device time per stage since enable */
     uint64_t launches[PHYS_STAGE_COUNT]; /* kernel launches (memsets included) per stage */

@@ -18,6 +18,7 @@ PHYS_ERR_NO_BODIES = -8
 
 SHAPE_NONE, SHAPE_SPHERE, SHAPE_BOX = 0, 1, 2
 FLAG_COLLISIONS, FLAG_GROUND_PLANE, FLAG_EXACT_ROTATION, FLAG_BROADPHASE_ONLY = 1, 2, 4, 8
+FLAG_SOLVER_PER_COLOR = 16
 GROUND_ID = 0xFFFFFFFF
 
 f32p = C.POINTER(C.c_float)
@@ -67,9 +68,9 @@ class PhysStats(C.Structure):
     ]
 
 
-STAGE_COUNT = 12
+STAGE_COUNT = 13
 STAGE_NAMES = ["step_full", "velocity_aabb", "grid", "pairs", "narrow", "color", "rows", "solve", "position",
-               "constraints", "misc", "solve_tail"]
+               "constraints", "misc", "solve_tail", "solve_flow"]
 
 
 class PhysProfile(C.Structure):

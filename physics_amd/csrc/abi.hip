@@ -361,6 +361,8 @@ int32_t phys_sync(phys_world* w) {
     ENTER(w);
     const int32_t rc = fetch_counters(w);
     if (rc != PHYS_OK) return rc;
+    if (w->h_counters->overflow & 16u)
+        return fail(PHYS_ERR_HIP, "contact solver hand-off timed out (k_solve_flow); velocities of this step are invalid");
     if (w->h_counters->overflow)
         return fail(PHYS_ERR_CAPACITY, "pair/manifold/colour capacity exceeded: raise phys_config.max_pairs / max_manifolds");
     return PHYS_OK;

@@ -335,6 +335,15 @@ int32_t collision_alloc(phys_world* w) {
         PHYS_HIP_TRY(w->row_normal.resize(3 * M));
         PHYS_HIP_TRY(w->row_data.resize(40 * M));
         PHYS_HIP_TRY(w->row_acc.resize(12 * M));
+        if (!(w->cfg.flags & PHYS_FLAG_SOLVER_PER_COLOR)) {
+            PHYS_HIP_TRY(w->row_ticket.resize(M));
+            PHYS_HIP_TRY(w->flow_vel.resize(8 * n));
+            PHYS_HIP_TRY(w->flow_acc.resize(16 * M));
+            // tags of an earlier scene must never look like tags of this one
+            PHYS_HIP_TRY(hipMemsetAsync(w->flow_vel.p, 0, 8 * n * sizeof(float), w->stream));
+            PHYS_HIP_TRY(hipMemsetAsync(w->flow_acc.p, 0, 16 * M * sizeof(float), w->stream));
+            w->flow_epoch = 0;
+        }
     }
     return PHYS_OK;
 }

@@ -12,6 +12,8 @@
 // Algorithmic bytes per manifold per iteration: row planes 12 + 12 (ids, count, normal) +
 // per point 40 (rA, rB, masses, bias) + 12 R + 12 W (accumulated impulses), + per body 48 (v, w R+W) +
 // 4 (inv mass) + 36 (inverse inertia).
+#include <cstdlib>
+
 #include "kernels.hpp"
 
 namespace phys {
@@ -45,7 +47,10 @@ __global__ __launch_bounds__(256) void k_rows_build(const StepCounters* __restri
                                                     const float* __restrict__ inv_inertia, uint32_t* __restrict__ row_a,
                                                     uint32_t* __restrict__ row_b, uint32_t* __restrict__ row_count,
                                                     float* __restrict__ row_normal, float* __restrict__ row_data,
-                                                    float* __restrict__ row_acc) {
+                                                    float* __restrict__ row_acc,
+                                                    const uint32_t* __restrict__ man_color,
+                                                    const unsigned long long* __restrict__ used,
+                                                    uint32_t* __restrict__ row_ticket /* null: per-colour solver */) {
     if (ctr->overflow) return;  // never solve a truncated set; phys_sync / phys_get_stats report it
     const uint32_t M = ctr->n_manifolds;
     for (uint32_t d = blockIdx.x * blockDim.x + threadIdx.x; d < M; d += gridDim.x * blockDim.x) {
@@ -72,6 +77,18 @@ __global__ __launch_bounds__(256) void k_rows_build(const StepCounters* __restri
     solver_manifold_t sm;
     solver_prep(&g, has_b, ld3(pos, a), xB, vel[8 * (size_t)a + 3], &IA, imb, &IB, &sp, &sm);
     row_a[d] = a; row_b[d] = b; row_count[d] = (uint32_t)sm.count;
+    if (row_ticket) {
+        // the colours in use at a body are exactly the colours of its manifolds (all distinct), so the rank of
+        // this row among the body's manifolds in solve order = number of its colours below this one
+        const unsigned long long below = (1ull << man_color[m]) - 1ull;
+        const unsigned long long ua = used[a];
+        uint32_t t = (uint32_t)__popcll(ua & below) | ((uint32_t)__popcll(ua) << 8);
+        if (has_b) {
+            const unsigned long long ub = used[b];
+            t |= ((uint32_t)__popcll(ub & below) << 16) | ((uint32_t)__popcll(ub) << 24);
+        }
+        row_ticket[d] = t;
+    }
     row_normal[0 * cap + d] = sm.n.x; row_normal[1 * cap + d] = sm.n.y; row_normal[2 * cap + d] = sm.n.z;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -127,8 +144,12 @@ __device__ __forceinline__ void load_row(RowRegs& R, uint32_t d, uint64_t cap, c
             c.rB = v3_make(r[3 * cap], r[4 * cap], r[5 * cap]);
             c.normal_mass = r[6 * cap]; c.tangent_mass[0] = r[7 * cap]; c.tangent_mass[1] = r[8 * cap];
             c.bias = r[9 * cap];
-            const float* acc = row_acc + (size_t)(k * kAccPlanesPerPoint) * cap + d;
-            c.pn = acc[0 * cap]; c.pt[0] = acc[1 * cap]; c.pt[1] = acc[2 * cap];
+            if (row_acc) {
+                const float* acc = row_acc + (size_t)(k * kAccPlanesPerPoint) * cap + d;
+                c.pn = acc[0 * cap]; c.pt[0] = acc[1 * cap]; c.pt[1] = acc[2 * cap];
+            } else {  // dataflow solver: impulses arrive as granules (zero in iteration 0)
+                c.pn = 0.0f; c.pt[0] = 0.0f; c.pt[1] = 0.0f;
+            }
         } else {
             c.rA = v3_make(0.0f, 0.0f, 0.0f); c.rB = v3_make(0.0f, 0.0f, 0.0f);
             c.normal_mass = 0.0f; c.tangent_mass[0] = 0.0f; c.tangent_mass[1] = 0.0f; c.bias = 0.0f;
@@ -226,6 +247,184 @@ __global__ __launch_bounds__(kTailThreads) void k_solve_tail(const StepCounters*
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Single-launch dataflow solver. Same arithmetic and the same ORDER OF UPDATES PER BODY as the per-colour
+// launches (iterations outermost, colours ascending), so the results are bit-identical; what changes is how
+// the order is enforced. Instead of a kernel boundary after every colour of every iteration (8 x n_colours
+// dependent launches of 5-20 us), every body carries a ticket: the k-th update of body A in solve order may
+// only be made by the row holding ticket k for A (k = iteration * deg(A) + rank of the row's colour among A's
+// colours; k_rows_build). In-flight velocities live in `flow_vel` as two 16-byte granules {x, y, z, tag} whose
+// tag = (epoch << 16) | number of updates applied, i.e. THE DATA IS ITS OWN READY FLAG: a row polls its bodies'
+// granules (sc1 loads: bypass the CU's L1) until both tags equal its ticket, solves, and stores them back
+// (sc1 = write-through stores) with tag + 1. One hop costs ~0.7-1.0 us (tools/hop_bench.hip) instead of a
+// launch, and rows of different colours / iterations overlap wherever the contact graph allows.
+//   * the FIRST update of a body reads the plain `vel` record (written by the previous kernel), the LAST one
+//     writes it (read by the next kernel): flow_vel never needs initialising; stale tags of earlier steps carry
+//     another epoch;
+//   * accumulated impulses cross iterations the same way ({pn, pt0, pt1, tag = iteration});
+//   * work items (iteration, chunk of 256*sub rows) are handed out by an atomic ticket in solve order, so every
+//     dependency of an item was taken EARLIER by a workgroup that is running: no co-residency assumption, no
+//     deadlock by construction; and every spin is bounded (timeout -> overflow bit 4 -> PHYS_ERR_HIP at sync).
+// Granule discipline follows the guide's data-tagged hand-off: each granule is written by ONE 16-byte sc1
+// store and only ever read by 16-byte sc1 loads.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ u32x4 ld_granule(__amdgpu_buffer_rsrc_t r, uint32_t byte_off) {
+    // aux: 16 = sc1 (served past the CU's L1), bit 31 = volatile (the compiler must re-issue it in every sweep)
+    return __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, (int)0x80000010);
+}
+__device__ __forceinline__ void st_granule(__amdgpu_buffer_rsrc_t r, uint32_t byte_off, v3 v, uint32_t tag) {
+    u32x4 g;
+    g.x = __float_as_uint(v.x); g.y = __float_as_uint(v.y); g.z = __float_as_uint(v.z); g.w = tag;
+    __builtin_amdgcn_raw_buffer_store_b128(g, r, byte_off, 0, 16);
+}
+
+constexpr uint32_t kFlowTimeoutTicks = 300000000u;  // 3 s of the 100 MHz wall clock
+
+template <bool DIAG>
+__global__ __launch_bounds__(256) void k_solve_flow(StepCounters* __restrict__ ctr, uint32_t iterations, uint32_t sub,
+                                                    uint32_t epoch, uint64_t cap, float friction,
+                                                    const uint32_t* __restrict__ row_a, const uint32_t* __restrict__ row_b,
+                                                    const uint32_t* __restrict__ row_count,
+                                                    const uint32_t* __restrict__ row_ticket,
+                                                    const float* __restrict__ row_normal,
+                                                    const float* __restrict__ row_data,
+                                                    const float* __restrict__ inv_inertia, uint32_t inertia_stride,
+                                                    float* vel, float* flow_vel, uint32_t n_bodies, float* flow_acc,
+                                                    uint32_t sleep_mid, uint32_t sleep_far) {
+    __shared__ uint32_t s_item;
+    if (ctr->overflow) return;
+    const uint32_t M = ctr->n_manifolds;
+    const uint32_t rows_per_item = blockDim.x * sub;
+    const uint32_t nchunks = (M + rows_per_item - 1) / rows_per_item;
+    const uint32_t total = nchunks * iterations;
+    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(flow_vel, 0, n_bodies * 32u, 0x00020000);
+    // flow_acc can exceed 4 GiB: a window of this item's rows is described per item below
+    const uint32_t etag = epoch << 16;
+    const unsigned long long t_start = wall_clock64();
+    for (;;) {
+        __syncthreads();
+        if (threadIdx.x == 0)
+            s_item = (__hip_atomic_load(&ctr->overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 16u)
+                         ? 0xFFFFFFFFu : atomicAdd(&ctr->flow_ticket, 1u);
+        __syncthreads();
+        const uint32_t L = s_item;
+        if (L >= total) return;
+        const uint32_t it = L / nchunks, chunk = L - it * nchunks;
+        const bool last_it = it + 1 == iterations;
+        const uint32_t item_first = chunk * rows_per_item;
+        const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(flow_acc + 16 * (size_t)item_first, 0,
+                                                                              rows_per_item * 64u, 0x00020000);
+        for (uint32_t sc = 0; sc < sub; ++sc) {
+            const uint32_t local = sc * blockDim.x + threadIdx.x;
+            const uint32_t d = item_first + local;
+            bool done = d >= M;
+            RowRegs R;
+            uint32_t tA = 0, tB = 0;
+            bool finalA = false, finalB = false;
+            m33 IA, IB;
+            float ima = 0.0f, imb = 0.0f;
+            v3 vA = v3_make(0.0f, 0.0f, 0.0f), wA = vA, vB = vA, wB = vA;
+            float massA = 0.0f, massB = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) { IA.m[k] = 0.0f; IB.m[k] = 0.0f; }
+            R.a = 0; R.b = PHYS_GROUND_ID; R.sm.count = 0; R.sm.has_b = 0;
+            if (!done) {
+                // everything that is constant during the solve: plain loads, in flight while the row waits
+                load_row(R, d, cap, row_a, row_b, row_count, row_normal, row_data, nullptr);
+                const uint32_t tk = row_ticket[d];
+                const uint32_t rankA = tk & 0xFFu, degA = (tk >> 8) & 0xFFu, rankB = (tk >> 16) & 0xFFu, degB = tk >> 24;
+                tA = it * degA + rankA;
+                finalA = last_it && rankA + 1 == degA;
+                IA = ld_inertia<DIAG>(inv_inertia, R.a * inertia_stride);
+                const BodyVel A0 = ld_vel(vel, R.a);  // v, w valid only for ticket 0; the masses always
+                ima = A0.inv_mass; massA = A0.mass; vA = A0.v; wA = A0.w;
+                if (R.sm.has_b) {
+                    tB = it * degB + rankB;
+                    finalB = last_it && rankB + 1 == degB;
+                    IB = ld_inertia<DIAG>(inv_inertia, R.b * inertia_stride);
+                    const BodyVel B0 = ld_vel(vel, R.b);
+                    imb = B0.inv_mass; massB = B0.mass; vB = B0.v; wB = B0.w;
+                }
+            }
+            const bool needA = tA != 0, needB = R.sm.has_b && tB != 0, needAcc = it != 0;
+            uint32_t sweeps = 0;
+            for (;;) {
+                uint32_t gap = 0;
+                if (!done) {
+                    u32x4 a0, a1, b0, b1, p[4];
+                    if (needA) { a0 = ld_granule(rv, R.a * 32u); a1 = ld_granule(rv, R.a * 32u + 16u); }
+                    if (needB) { b0 = ld_granule(rv, R.b * 32u); b1 = ld_granule(rv, R.b * 32u + 16u); }
+                    if (needAcc) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) if (k < R.sm.count) p[k] = ld_granule(ra, local * 64u + 16u * k);
+                    }
+                    bool ok = true;
+                    if (needA) {
+                        const uint32_t want = etag | tA;
+                        ok = ok && a0.w == want && a1.w == want;
+                        const uint32_t seen = (a0.w >> 16) == epoch ? (a0.w & 0xFFFFu) : 0u;
+                        gap = tA > seen ? tA - seen : 1u;
+                    }
+                    if (needB) {
+                        const uint32_t want = etag | tB;
+                        ok = ok && b0.w == want && b1.w == want;
+                        const uint32_t seen = (b0.w >> 16) == epoch ? (b0.w & 0xFFFFu) : 0u;
+                        const uint32_t g = tB > seen ? tB - seen : 1u;
+                        gap = g > gap ? g : gap;
+                    }
+                    if (needAcc) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) if (k < R.sm.count) ok = ok && p[k].w == (etag | it);
+                    }
+                    if (ok) {
+                        if (needA) { vA = v3_make(__uint_as_float(a0.x), __uint_as_float(a0.y), __uint_as_float(a0.z));
+                                     wA = v3_make(__uint_as_float(a1.x), __uint_as_float(a1.y), __uint_as_float(a1.z)); }
+                        if (needB) { vB = v3_make(__uint_as_float(b0.x), __uint_as_float(b0.y), __uint_as_float(b0.z));
+                                     wB = v3_make(__uint_as_float(b1.x), __uint_as_float(b1.y), __uint_as_float(b1.z)); }
+                        if (needAcc) {
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) if (k < R.sm.count) {
+                                R.sm.row[k].pn = __uint_as_float(p[k].x);
+                                R.sm.row[k].pt[0] = __uint_as_float(p[k].y);
+                                R.sm.row[k].pt[1] = __uint_as_float(p[k].z);
+                            }
+                        }
+                        solve_manifold(&R.sm, friction, ima, &IA, imb, &IB, &vA, &wA, &vB, &wB);
+                        // publish: bodies first (they are what other rows wait for)
+                        if (finalA) { BodyVel o; o.v = vA; o.inv_mass = ima; o.w = wA; o.mass = massA; st_vel(vel, R.a, o); }
+                        else { st_granule(rv, R.a * 32u, vA, etag | (tA + 1u)); st_granule(rv, R.a * 32u + 16u, wA, etag | (tA + 1u)); }
+                        if (R.sm.has_b) {
+                            if (finalB) { BodyVel o; o.v = vB; o.inv_mass = imb; o.w = wB; o.mass = massB; st_vel(vel, R.b, o); }
+                            else { st_granule(rv, R.b * 32u, vB, etag | (tB + 1u)); st_granule(rv, R.b * 32u + 16u, wB, etag | (tB + 1u)); }
+                        }
+                        if (!last_it) {
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) if (k < R.sm.count)
+                                st_granule(ra, local * 64u + 16u * k,
+                                           v3_make(R.sm.row[k].pn, R.sm.row[k].pt[0], R.sm.row[k].pt[1]), etag | (it + 1u));
+                        }
+                        done = true;
+                    }
+                }
+                if (__all(done)) break;
+                // back off in proportion to how many hops away the nearest waiting lane is
+                if (__any(!done && gap <= 1u)) __builtin_amdgcn_s_sleep(1);
+                else if (__any(!done && gap <= 4u)) { for (uint32_t q = 0; q < sleep_mid; ++q) __builtin_amdgcn_s_sleep(8); }
+                else { for (uint32_t q = 0; q < sleep_far; ++q) __builtin_amdgcn_s_sleep(8); }
+                if ((++sweeps & 63u) == 0u) {
+                    const bool dead = (wall_clock64() - t_start > kFlowTimeoutTicks) ||
+                                      (__hip_atomic_load(&ctr->overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 16u);
+                    if (dead) {  // wave-uniform: both inputs are
+                        if ((threadIdx.x & 63u) == 0u) atomicOr(&ctr->overflow, 16u);
+                        done = true;
+                    }
+                }
+            }
+        }
+    }
+}
+
 // Launch sizes come from the HINT (counters of an earlier step, read back asynchronously); every kernel
 // takes its real ranges from the device-side counters, so a stale hint costs speed, never correctness.
 void launch_solver(phys_world* w, float dt) {
@@ -251,9 +450,46 @@ void launch_solver(phys_world* w, float dt) {
         return dim3((unsigned)(b ? b : 1));
     };
     const uint64_t m_hint = h.valid ? h.n_manifolds : cap;
+    // the dataflow kernel wins while a colour class is too small to fill the chip (launch / latency bound);
+    // beyond that the per-colour launches stream better. Both give the same bits, so the choice may change
+    // from step to step.
+    const bool flow = !(w->cfg.flags & PHYS_FLAG_SOLVER_PER_COLOR) && h.valid && m_hint <= 400000;
     { PHYS_PROF(w, PHYS_STAGE_ROWS); hipLaunchKernelGGL(k_rows_build, grid_for_count(m_hint), tb, 0, s, w->counters.p, cap, sp, w->row_src.p, w->man_a.p, w->man_b.p, w->man_count.p,
                        w->man_normal.p, w->man_points.p, w->pos.p, w->vel.p, w->inv_inertia.p, w->row_a.p,
-                       w->row_b.p, w->row_count.p, w->row_normal.p, w->row_data.p, w->row_acc.p); }
+                       w->row_b.p, w->row_count.p, w->row_normal.p, w->row_data.p, w->row_acc.p, w->man_color.p,
+                       w->color_state.p, flow ? w->row_ticket.p : nullptr); }
+    if (flow) {
+        if (w->cfg.solver_iterations == 0) return;
+        if (++w->flow_epoch > 0xFFFFu) {  // tags would repeat: forget every old one
+            (void)hipMemsetAsync(w->flow_vel.p, 0, 8 * w->n * sizeof(float), s);
+            (void)hipMemsetAsync(w->flow_acc.p, 0, 16 * cap * sizeof(float), s);
+            w->flow_epoch = 1;
+        }
+        static const uint32_t k_sub = getenv("PHYS_FLOW_SUB") ? atoi(getenv("PHYS_FLOW_SUB")) : 0;
+        static const uint32_t k_mid = getenv("PHYS_FLOW_MID") ? atoi(getenv("PHYS_FLOW_MID")) : 5;
+        static const uint32_t k_far = getenv("PHYS_FLOW_FAR") ? atoi(getenv("PHYS_FLOW_FAR")) : 32;
+        static const uint32_t e_grid = getenv("PHYS_FLOW_GRID") ? atoi(getenv("PHYS_FLOW_GRID")) : 0;
+        static const uint32_t e_threads = getenv("PHYS_FLOW_THREADS") ? atoi(getenv("PHYS_FLOW_THREADS")) : 0;
+        // about one wave per SIMD or less: waiting waves must not crowd out the ones that can run
+        const uint32_t k_threads = e_threads ? e_threads : (m_hint <= 20000 ? 64u : 256u);
+        const uint32_t k_grid = e_grid ? e_grid : (k_threads == 64 ? 192u : 256u);
+        const dim3 ftb(k_threads);
+        const uint32_t sub = k_sub ? k_sub : 1u;
+        uint64_t items = (uint64_t)w->cfg.solver_iterations * ((m_hint * 5 / 4 + k_threads * sub - 1) / (k_threads * sub)) + 1;
+        if (items > k_grid) items = k_grid;  // more than can be resident: the rest of the items are taken by the same workgroups
+        PHYS_PROF(w, PHYS_STAGE_SOLVE_FLOW);
+        if (diag)
+            hipLaunchKernelGGL(k_solve_flow<true>, dim3((unsigned)items), ftb, 0, s, w->counters.p, w->cfg.solver_iterations, sub,
+                               w->flow_epoch, cap, sp.friction, w->row_a.p, w->row_b.p, w->row_count.p, w->row_ticket.p,
+                               w->row_normal.p, w->row_data.p, w->inv_inertia_diag.p, istride, w->vel.p, w->flow_vel.p,
+                               (uint32_t)w->n, w->flow_acc.p, k_mid, k_far);
+        else
+            hipLaunchKernelGGL(k_solve_flow<false>, dim3((unsigned)items), ftb, 0, s, w->counters.p, w->cfg.solver_iterations, sub,
+                               w->flow_epoch, cap, sp.friction, w->row_a.p, w->row_b.p, w->row_count.p, w->row_ticket.p,
+                               w->row_normal.p, w->row_data.p, w->inv_inertia.p, 1u, w->vel.p, w->flow_vel.p,
+                               (uint32_t)w->n, w->flow_acc.p, k_mid, k_far);
+        return;
+    }
     // colours [0, big) get a launch each; [big, n_colours) go through the single-workgroup tail
     constexpr uint32_t kTailMax = 512;  // manifolds per colour the tail should take: one trip of the workgroup
     uint32_t big = 0;

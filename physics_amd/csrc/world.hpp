@@ -62,10 +62,11 @@ struct StepCounters {
     uint32_t n_uncolored;    // manifolds still uncoloured (colouring loop)
     uint32_t n_colors;       // colours in use
     uint32_t color_rounds;
-    uint32_t overflow;       // bit 0 pairs, bit 1 manifolds, bit 2 colours, bit 3 cross pairs
+    uint32_t overflow;       // bit 0 pairs, bit 1 manifolds, bit 2 colours, bit 3 cross pairs, bit 4 solver hand-off timeout
     uint32_t n_halo;         // halo records packed
     uint32_t n_cross_pairs;
     uint32_t n_ground_manifolds;
+    uint32_t flow_ticket;    // k_solve_flow: next (iteration, row chunk) item to hand to a workgroup
     uint32_t color_count[kMaxColors];  // manifolds per colour
     uint32_t color_start[kMaxColors + 1];
     // LAST member: survives the per-step reset (only the bytes before it are zeroed), so a wave issues the
@@ -200,6 +201,13 @@ struct phys_world {
     phys::DevBuf<float> row_normal;  // 3 per manifold (SoA planes)
     phys::DevBuf<float> row_data;    // per point-slot planes: rA(3) rB(3) nmass tmass0 tmass1 bias
     phys::DevBuf<float> row_acc;     // per point-slot planes: pn pt0 pt1
+    // single-launch dataflow solver (k_solve_flow): in-flight body velocities and accumulated impulses travel
+    // between workgroups as 16-byte granules {x, y, z, tag} (the tag says WHICH update of that body / row the
+    // data is, so the data is its own ready flag)
+    phys::DevBuf<uint32_t> row_ticket;  // per row: rank of the row among body A's / B's manifolds and their counts
+    phys::DevBuf<float> flow_vel;       // 8 per body: {v.xyz, tag} {w.xyz, tag}
+    phys::DevBuf<float> flow_acc;       // 16 per manifold row: 4 x {pn, pt0, pt1, tag}
+    uint32_t flow_epoch = 0;            // solves since the buffers were cleared (upper half of every tag)
     // multi-GPU halo
     phys::DevBuf<uint32_t> cross_pairs;
     uint64_t max_cross_pairs = 0;

@@ -158,3 +158,56 @@ def test_double_run_determinism():
         out.append(w.get_transforms())
         w.close()
     assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+
+
+def test_dataflow_and_per_colour_solver_are_bit_identical():
+    """The single-launch dataflow solver (default) and one launch per colour class (PHYS_FLAG_SOLVER_PER_COLOR)
+    apply the same updates to every body in the same order: identical bits, and both equal the oracle."""
+    import physics_amd
+    from physics_amd import scenes
+    sc = scenes.c3(20, 16, 20)
+    worlds = [physics_amd.World(sc.config()),
+              physics_amd.World(sc.config(flags=sc.flags | physics_amd.FLAG_SOLVER_PER_COLOR))]
+    for w in worlds:
+        sc.populate(w)
+    for k in range(4):
+        for w in worlds:
+            w.update_n(DT, 60)
+            w.sync()
+        for a, b in zip(worlds[0].get_transforms() + worlds[0].get_velocities(),
+                        worlds[1].get_transforms() + worlds[1].get_velocities()):
+            assert np.array_equal(a, b), f"solver modes differ after {60 * (k + 1)} steps"
+    assert worlds[0].get_stats().n_manifolds > sc.n  # a contact-rich state was reached
+    prof = []
+    for w in worlds:
+        w.profile_enable(True)
+        w.update_n(DT, 4)
+        prof.append(w.profile_get()[0])
+    assert "solve_flow" in prof[0] and "solve" not in prof[0]
+    assert "solve_flow" not in prof[1] and ("solve" in prof[1] or "solve_tail" in prof[1])
+
+
+def test_full_inertia_tensors_and_unequal_masses_bit_exact():
+    """Non-diagonal inertia tensors and per-body masses: the general (non-DIAG) solver kernels, both modes."""
+    import physics_amd
+    rng = np.random.default_rng(11)
+    n = 300
+    pos = np.stack([rng.uniform(-5, 5, n), rng.uniform(1.5, 25, n), rng.uniform(-5, 5, n)], 1).astype(np.float32)
+    st = rng.integers(1, 3, size=n).astype(np.uint32)
+    he = rng.uniform(0.5, 1.0, size=(n, 3)).astype(np.float32)
+    mass = rng.uniform(0.5, 3.0, size=n).astype(np.float32)
+    a = rng.normal(scale=0.2, size=(n, 3, 3))
+    inertia = (np.eye(3)[None] * rng.uniform(0.5, 2.0, size=(n, 1, 1)) + a @ a.transpose(0, 2, 1)).astype(np.float32)
+    for extra in (0, physics_amd.FLAG_SOLVER_PER_COLOR):
+        cfg = lambda: physics_amd.default_config(
+            flags=physics_amd.FLAG_COLLISIONS | physics_amd.FLAG_GROUND_PLANE | extra, gravity_offset=(0, 0, 0),
+            max_pairs=64 * n)
+        w, o = _worlds(cfg)
+        for x in (w, o):
+            x.set_bodies(pos, mass=mass, inertia=inertia.reshape(n, 9), shape_type=st, half_extent=he)
+        for k in range(4):
+            w.update_n(DT, 50)
+            o.update_n(DT, 50)
+            w.sync()
+            _compare_state(w, o, f"full inertia, flags +{extra}, step {50 * (k + 1)}")
+        assert w.get_stats().n_contacts > 50

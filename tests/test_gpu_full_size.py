@@ -165,7 +165,7 @@ def test_stats_and_stage_profile_are_consistent():
     w.profile_enable(True)
     w.update_n(DT, 10)
     prof, steps = w.profile_get()
-    assert steps == 10 and "solve" in prof or "solve_tail" in prof
+    assert steps == 10 and ("solve_flow" in prof or "solve" in prof or "solve_tail" in prof)
     assert all(ms >= 0 and n > 0 for ms, n in prof.values())
     counts = w.get_color_counts()
     st = w.get_stats()
