@@ -331,17 +331,16 @@ int32_t collision_alloc(phys_world* w) {
             w->color_epoch = 0;
         }
         PHYS_HIP_TRY(w->color_block_hist.resize((size_t)kMaxColors * 512));
-        PHYS_HIP_TRY(w->row_a.resize(M)); PHYS_HIP_TRY(w->row_b.resize(M)); PHYS_HIP_TRY(w->row_count.resize(M));
-        PHYS_HIP_TRY(w->row_normal.resize(3 * M));
-        PHYS_HIP_TRY(w->row_data.resize(40 * M));
-        PHYS_HIP_TRY(w->row_acc.resize(12 * M));
-        if (!(w->cfg.flags & PHYS_FLAG_SOLVER_PER_COLOR)) {
-            PHYS_HIP_TRY(w->row_ticket.resize(M));
+        PHYS_HIP_TRY(w->row_hdr.resize(4 * M)); PHYS_HIP_TRY(w->row_n.resize(4 * M));
+        PHYS_HIP_TRY(w->row_pt.resize(32 * M)); PHYS_HIP_TRY(w->row_tb.resize(8 * M));
+        PHYS_HIP_TRY(w->row_acc.resize(16 * M));
+        w->flow_vel.free();
+        // the dataflow solver addresses row_acc / flow_vel through 32-bit buffer offsets
+        if (!(w->cfg.flags & PHYS_FLAG_SOLVER_PER_COLOR) && 64 * M < 0xFFFFFFFFull && 32 * n < 0xFFFFFFFFull) {
             PHYS_HIP_TRY(w->flow_vel.resize(8 * n));
-            PHYS_HIP_TRY(w->flow_acc.resize(16 * M));
             // tags of an earlier scene must never look like tags of this one
             PHYS_HIP_TRY(hipMemsetAsync(w->flow_vel.p, 0, 8 * n * sizeof(float), w->stream));
-            PHYS_HIP_TRY(hipMemsetAsync(w->flow_acc.p, 0, 16 * M * sizeof(float), w->stream));
+            PHYS_HIP_TRY(hipMemsetAsync(w->row_acc.p, 0, 16 * M * sizeof(float), w->stream));
             w->flow_epoch = 0;
         }
     }

@@ -5,25 +5,24 @@
 // parallel (they share no body, so there are no float atomics and the result is independent of the
 // schedule), points of a manifold in index order inside one lane.
 //
-// Data layout: after colouring, manifolds are renumbered colour-major (row d = colour start + slot in
-// colour). Solver rows are plane-major SoA over d, so each of the 8 x n_colours solve launches streams
-// its rows with unit stride; only the body velocities (24 B read + 24 B written per body) and the
-// inverse mass / inertia are gathered by body id.
-// Algorithmic bytes per manifold per iteration: row planes 12 + 12 (ids, count, normal) +
-// per point 40 (rA, rB, masses, bias) + 12 R + 12 W (accumulated impulses), + per body 48 (v, w R+W) +
-// 4 (inv mass) + 36 (inverse inertia).
-#include <cstdlib>
-
+// Row storage: after colouring, manifolds are renumbered colour-major (row d = colour start + slot in
+// colour). Everything a solve needs per row is kept as 16-BYTE elements in plane-major arrays over d (stride =
+// cap), so a lane fetches a row with ~10 dwordx4 loads (a wave: 1 KiB contiguous per load) instead of ~45
+// dword loads - the row solve is a long dependent chain at one wave per SIMD, and the number of memory
+// instructions in front of it is what its latency is made of:
+//     row_hdr uint4  [d]              {body a, body b, point count, update tickets (k_solve_flow)}
+//     row_n   float4 [d]              {normal xyz, 0}
+//     row_pt  float4 [(2k)*cap + d]   {rA xyz, normal mass}          point k = 0..3
+//                    [(2k+1)*cap + d] {rB xyz, tangent mass 0}
+//     row_tb  float4 [d]              {tangent mass 1, bias} of points 0 and 1;  [cap + d]: points 2 and 3
+//     row_acc float4 [k*cap + d]      {pn, pt0, pt1, tag}            accumulated impulses of point k
+// Only the body velocities (32-byte records) and the inverse inertia are gathered by body id.
+// Algorithmic bytes per manifold per iteration: ids, count, normal 24 + per point 40 (rA, rB,
+// masses, bias) + 12 R + 12 W (accumulated impulses), + per body 48 (v, w R+W) + 4 (inv mass) + 12 / 36
+// (inverse inertia diagonal / full).
 #include "kernels.hpp"
 
 namespace phys {
-
-struct ColorTable {
-    uint32_t start[kMaxColors + 1];
-};
-
-constexpr int kRowPlanesPerPoint = 10;  // rA xyz, rB xyz, normal mass, tangent mass 0/1, bias
-constexpr int kAccPlanesPerPoint = 3;   // pn, pt0, pt1
 
 // inverse inertia of one body. DIAG: every body's tensor is diagonal (the reference's only case: identity,
 // rigid_body.rs:71), stored as one float4 per body = 16 B and one sector per gather instead of 36 B / two.
@@ -36,76 +35,6 @@ __device__ __forceinline__ m33 ld_m33(const float* __restrict__ p, uint32_t i) {
     for (int k = 0; k < 9; ++k) M.m[k] = p[9 * (size_t)i + k];
     return M;
 }
-
-__global__ __launch_bounds__(256) void k_rows_build(const StepCounters* __restrict__ ctr, uint64_t cap, solve_params_t sp,
-                                                    const uint32_t* __restrict__ row_src,
-                                                    const uint32_t* __restrict__ man_a, const uint32_t* __restrict__ man_b,
-                                                    const uint32_t* __restrict__ man_count,
-                                                    const float* __restrict__ man_normal,
-                                                    const float* __restrict__ man_points, const float* __restrict__ pos,
-                                                    const float* __restrict__ vel,
-                                                    const float* __restrict__ inv_inertia, uint32_t* __restrict__ row_a,
-                                                    uint32_t* __restrict__ row_b, uint32_t* __restrict__ row_count,
-                                                    float* __restrict__ row_normal, float* __restrict__ row_data,
-                                                    float* __restrict__ row_acc,
-                                                    const uint32_t* __restrict__ man_color,
-                                                    const unsigned long long* __restrict__ used,
-                                                    uint32_t* __restrict__ row_ticket /* null: per-colour solver */) {
-    if (ctr->overflow) return;  // never solve a truncated set; phys_sync / phys_get_stats report it
-    const uint32_t M = ctr->n_manifolds;
-    for (uint32_t d = blockIdx.x * blockDim.x + threadIdx.x; d < M; d += gridDim.x * blockDim.x) {
-    const uint32_t m = row_src[d];
-    manifold_t g;
-    const uint32_t a = man_a[m], b = man_b[m];
-    g.count = (int)man_count[m];
-    g.normal = ld3(man_normal, m);
-    const float4* pp = reinterpret_cast<const float4*>(man_points) + 4 * (size_t)m;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const float4 p = pp[k];
-        g.pt[k] = v3_make(p.x, p.y, p.z);
-        g.depth[k] = p.w;
-    }
-    const int has_b = b != PHYS_GROUND_ID;
-    const m33 IA = ld_m33(inv_inertia, a);
-    m33 IB;
-#pragma unroll
-    for (int k = 0; k < 9; ++k) IB.m[k] = 0.0f;
-    float imb = 0.0f;
-    v3 xB = v3_make(0.0f, 0.0f, 0.0f);
-    if (has_b) { IB = ld_m33(inv_inertia, b); imb = vel[8 * (size_t)b + 3]; xB = ld3(pos, b); }
-    solver_manifold_t sm;
-    solver_prep(&g, has_b, ld3(pos, a), xB, vel[8 * (size_t)a + 3], &IA, imb, &IB, &sp, &sm);
-    row_a[d] = a; row_b[d] = b; row_count[d] = (uint32_t)sm.count;
-    if (row_ticket) {
-        // the colours in use at a body are exactly the colours of its manifolds (all distinct), so the rank of
-        // this row among the body's manifolds in solve order = number of its colours below this one
-        const unsigned long long below = (1ull << man_color[m]) - 1ull;
-        const unsigned long long ua = used[a];
-        uint32_t t = (uint32_t)__popcll(ua & below) | ((uint32_t)__popcll(ua) << 8);
-        if (has_b) {
-            const unsigned long long ub = used[b];
-            t |= ((uint32_t)__popcll(ub & below) << 16) | ((uint32_t)__popcll(ub) << 24);
-        }
-        row_ticket[d] = t;
-    }
-    row_normal[0 * cap + d] = sm.n.x; row_normal[1 * cap + d] = sm.n.y; row_normal[2 * cap + d] = sm.n.z;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        if (k < sm.count) {
-            float* r = row_data + (size_t)(k * kRowPlanesPerPoint) * cap + d;
-            const contact_row_t& c = sm.row[k];
-            r[0 * cap] = c.rA.x; r[1 * cap] = c.rA.y; r[2 * cap] = c.rA.z;
-            r[3 * cap] = c.rB.x; r[4 * cap] = c.rB.y; r[5 * cap] = c.rB.z;
-            r[6 * cap] = c.normal_mass; r[7 * cap] = c.tangent_mass[0]; r[8 * cap] = c.tangent_mass[1];
-            r[9 * cap] = c.bias;
-            float* acc = row_acc + (size_t)(k * kAccPlanesPerPoint) * cap + d;
-            acc[0 * cap] = 0.0f; acc[1 * cap] = 0.0f; acc[2 * cap] = 0.0f;
-        }
-    }
-    }
-}
-
 template <>
 __device__ __forceinline__ m33 ld_inertia<false>(const float* __restrict__ p, uint32_t i) { return ld_m33(p, i); }
 template <>
@@ -118,36 +47,118 @@ __device__ __forceinline__ m33 ld_inertia<true>(const float* __restrict__ p, uin
     return M;
 }
 
+struct RowArrays {
+    uint4* hdr;
+    float4* n;
+    float4* pt;
+    float4* tb;
+    float4* acc;
+    uint64_t cap;
+};
+
+__global__ __launch_bounds__(256) void k_rows_build(const StepCounters* __restrict__ ctr, RowArrays rows, solve_params_t sp,
+                                                    const uint32_t* __restrict__ row_src,
+                                                    const uint32_t* __restrict__ man_a, const uint32_t* __restrict__ man_b,
+                                                    const uint32_t* __restrict__ man_count,
+                                                    const float* __restrict__ man_normal,
+                                                    const float* __restrict__ man_points, const float* __restrict__ pos,
+                                                    const float* __restrict__ vel,
+                                                    const float* __restrict__ inv_inertia,
+                                                    const uint32_t* __restrict__ man_color,
+                                                    const unsigned long long* __restrict__ used,
+                                                    int flow /* 1: k_solve_flow runs this step (tickets, no zeroed impulses) */) {
+    if (ctr->overflow) return;  // never solve a truncated set; phys_sync / phys_get_stats report it
+    const uint32_t M = ctr->n_manifolds;
+    const uint64_t cap = rows.cap;
+    for (uint32_t d = blockIdx.x * blockDim.x + threadIdx.x; d < M; d += gridDim.x * blockDim.x) {
+        const uint32_t m = row_src[d];
+        manifold_t g;
+        const uint32_t a = man_a[m], b = man_b[m];
+        g.count = (int)man_count[m];
+        g.normal = ld3(man_normal, m);
+        const float4* pp = reinterpret_cast<const float4*>(man_points) + 4 * (size_t)m;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float4 p = pp[k];
+            g.pt[k] = v3_make(p.x, p.y, p.z);
+            g.depth[k] = p.w;
+        }
+        const int has_b = b != PHYS_GROUND_ID;
+        const m33 IA = ld_m33(inv_inertia, a);
+        m33 IB;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) IB.m[k] = 0.0f;
+        float imb = 0.0f;
+        v3 xB = v3_make(0.0f, 0.0f, 0.0f);
+        if (has_b) { IB = ld_m33(inv_inertia, b); imb = vel[8 * (size_t)b + 3]; xB = ld3(pos, b); }
+        solver_manifold_t sm;
+        solver_prep(&g, has_b, ld3(pos, a), xB, vel[8 * (size_t)a + 3], &IA, imb, &IB, &sp, &sm);
+        uint32_t ticket = 0;
+        if (flow) {
+            // the colours in use at a body are exactly the colours of its manifolds (all distinct), so the rank of
+            // this row among the body's manifolds in solve order = number of its colours below this one
+            const unsigned long long below = (1ull << man_color[m]) - 1ull;
+            const unsigned long long ua = used[a];
+            ticket = (uint32_t)__popcll(ua & below) | ((uint32_t)__popcll(ua) << 8);
+            if (has_b) {
+                const unsigned long long ub = used[b];
+                ticket |= ((uint32_t)__popcll(ub & below) << 16) | ((uint32_t)__popcll(ub) << 24);
+            }
+        }
+        rows.hdr[d] = make_uint4(a, b, (uint32_t)sm.count, ticket);
+        rows.n[d] = make_float4(sm.n.x, sm.n.y, sm.n.z, 0.0f);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (k < sm.count) {
+                const contact_row_t& c = sm.row[k];
+                rows.pt[(size_t)(2 * k) * cap + d] = make_float4(c.rA.x, c.rA.y, c.rA.z, c.normal_mass);
+                rows.pt[(size_t)(2 * k + 1) * cap + d] = make_float4(c.rB.x, c.rB.y, c.rB.z, c.tangent_mass[0]);
+                if (!flow) rows.acc[(size_t)k * cap + d] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            }
+        }
+        rows.tb[d] = make_float4(sm.row[0].tangent_mass[1], sm.row[0].bias, sm.row[1].tangent_mass[1], sm.row[1].bias);
+        if (sm.count > 2)
+            rows.tb[cap + d] = make_float4(sm.row[2].tangent_mass[1], sm.row[2].bias, sm.row[3].tangent_mass[1], sm.row[3].bias);
+    }
+}
+
 // one manifold row d of the colour-major numbering, in registers
 struct RowRegs {
-    uint32_t a, b;
+    uint32_t a, b, ticket;
     solver_manifold_t sm;
 };
 
-// part 1: everything that does NOT depend on body velocities (can be fetched a phase ahead)
-__device__ __forceinline__ void load_row(RowRegs& R, uint32_t d, uint64_t cap, const uint32_t* __restrict__ row_a,
-                                         const uint32_t* __restrict__ row_b, const uint32_t* __restrict__ row_count,
-                                         const float* __restrict__ row_normal, const float* __restrict__ row_data,
-                                         const float* __restrict__ row_acc) {
-    R.a = row_a[d]; R.b = row_b[d];
+// everything of a row that does NOT depend on body velocities. ACC: also the accumulated impulses (plain loads;
+// k_solve_flow receives them as tagged granules instead)
+template <bool ACC>
+__device__ __forceinline__ void load_row(RowRegs& R, uint32_t d, const RowArrays& rows) {
+    const uint64_t cap = rows.cap;
+    const uint4 h = rows.hdr[d];
+    R.a = h.x; R.b = h.y; R.ticket = h.w;
     solver_manifold_t& sm = R.sm;
-    sm.count = (int)row_count[d];
+    sm.count = (int)h.z;
     sm.has_b = R.b != PHYS_GROUND_ID;
-    sm.n = v3_make(row_normal[0 * cap + d], row_normal[1 * cap + d], row_normal[2 * cap + d]);
-    tangent_basis(sm.n, &sm.t1, &sm.t2);  // same inputs as solver_prep => same bits as the stored basis
+    const float4 nn = rows.n[d];
+    sm.n = v3_make(nn.x, nn.y, nn.z);
+    tangent_basis(sm.n, &sm.t1, &sm.t2);  // same inputs as solver_prep => same bits as the basis used there
+    const float4 t01 = rows.tb[d];
+    float4 t23 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (sm.count > 2) t23 = rows.tb[cap + d];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         contact_row_t& c = sm.row[k];
         if (k < sm.count) {
-            const float* r = row_data + (size_t)(k * kRowPlanesPerPoint) * cap + d;
-            c.rA = v3_make(r[0 * cap], r[1 * cap], r[2 * cap]);
-            c.rB = v3_make(r[3 * cap], r[4 * cap], r[5 * cap]);
-            c.normal_mass = r[6 * cap]; c.tangent_mass[0] = r[7 * cap]; c.tangent_mass[1] = r[8 * cap];
-            c.bias = r[9 * cap];
-            if (row_acc) {
-                const float* acc = row_acc + (size_t)(k * kAccPlanesPerPoint) * cap + d;
-                c.pn = acc[0 * cap]; c.pt[0] = acc[1 * cap]; c.pt[1] = acc[2 * cap];
-            } else {  // dataflow solver: impulses arrive as granules (zero in iteration 0)
+            const float4 p0 = rows.pt[(size_t)(2 * k) * cap + d];
+            const float4 p1 = rows.pt[(size_t)(2 * k + 1) * cap + d];
+            c.rA = v3_make(p0.x, p0.y, p0.z); c.normal_mass = p0.w;
+            c.rB = v3_make(p1.x, p1.y, p1.z); c.tangent_mass[0] = p1.w;
+            const float4 t = k < 2 ? t01 : t23;
+            c.tangent_mass[1] = (k & 1) ? t.z : t.x;
+            c.bias = (k & 1) ? t.w : t.y;
+            if (ACC) {
+                const float4 acc = rows.acc[(size_t)k * cap + d];
+                c.pn = acc.x; c.pt[0] = acc.y; c.pt[1] = acc.z;
+            } else {
                 c.pn = 0.0f; c.pt[0] = 0.0f; c.pt[1] = 0.0f;
             }
         } else {
@@ -158,12 +169,14 @@ __device__ __forceinline__ void load_row(RowRegs& R, uint32_t d, uint64_t cap, c
     }
 }
 
-// part 2: gather the two bodies, solve_manifold, write velocities and accumulated impulses back
+// gather the two bodies, solve_manifold, write velocities and accumulated impulses back
 template <bool DIAG>
-__device__ __forceinline__ void solve_loaded_row(RowRegs& R, uint32_t d, uint64_t cap, float friction,
-                                                 float* __restrict__ row_acc, const float* __restrict__ inv_inertia,
-                                                 uint32_t inertia_stride /* 0: one tensor shared by every body */,
-                                                 float* __restrict__ vel) {
+__device__ __forceinline__ void solve_row(uint32_t d, const RowArrays& rows, float friction,
+                                          const float* __restrict__ inv_inertia,
+                                          uint32_t inertia_stride /* 0: one tensor shared by every body */,
+                                          float* __restrict__ vel) {
+    RowRegs R;
+    load_row<true>(R, d, rows);
     solver_manifold_t& sm = R.sm;
     const uint32_t a = R.a, b = R.b;
     const m33 IA = ld_inertia<DIAG>(inv_inertia, a * inertia_stride);
@@ -182,38 +195,20 @@ __device__ __forceinline__ void solve_loaded_row(RowRegs& R, uint32_t d, uint64_
     st_vel(vel, a, A);
     if (sm.has_b) { B.v = vB; B.w = wB; st_vel(vel, b, B); }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        if (k < sm.count) {
-            float* acc = row_acc + (size_t)(k * kAccPlanesPerPoint) * cap + d;
-            acc[0 * cap] = sm.row[k].pn; acc[1 * cap] = sm.row[k].pt[0]; acc[2 * cap] = sm.row[k].pt[1];
-        }
-    }
-}
-
-template <bool DIAG>
-__device__ __forceinline__ void solve_row(uint32_t d, uint64_t cap, float friction, const uint32_t* __restrict__ row_a,
-                                          const uint32_t* __restrict__ row_b, const uint32_t* __restrict__ row_count,
-                                          const float* __restrict__ row_normal, const float* __restrict__ row_data,
-                                          float* __restrict__ row_acc, const float* __restrict__ inv_inertia,
-                                          uint32_t inertia_stride, float* __restrict__ vel) {
-    RowRegs R;
-    load_row(R, d, cap, row_a, row_b, row_count, row_normal, row_data, row_acc);
-    solve_loaded_row<DIAG>(R, d, cap, friction, row_acc, inv_inertia, inertia_stride, vel);
+    for (int k = 0; k < 4; ++k)
+        if (k < sm.count)
+            rows.acc[(size_t)k * rows.cap + d] = make_float4(sm.row[k].pn, sm.row[k].pt[0], sm.row[k].pt[1], 0.0f);
 }
 
 // one colour of one iteration; the row range comes from the device-side colour table
 template <bool DIAG>
-__global__ __launch_bounds__(256) void k_solve_color(const StepCounters* __restrict__ ctr, uint32_t col, uint64_t cap,
-                                                     float friction, const uint32_t* __restrict__ row_a,
-                                                     const uint32_t* __restrict__ row_b,
-                                                     const uint32_t* __restrict__ row_count,
-                                                     const float* __restrict__ row_normal,
-                                                     const float* __restrict__ row_data, float* __restrict__ row_acc,
-                                                     const float* __restrict__ inv_inertia, uint32_t inertia_stride, float* __restrict__ vel) {
+__global__ __launch_bounds__(256) void k_solve_color(const StepCounters* __restrict__ ctr, uint32_t col, RowArrays rows,
+                                                     float friction, const float* __restrict__ inv_inertia,
+                                                     uint32_t inertia_stride, float* __restrict__ vel) {
     if (ctr->overflow) return;
     const uint32_t start = ctr->color_start[col], end = ctr->color_start[col + 1];
     for (uint32_t d = start + blockIdx.x * blockDim.x + threadIdx.x; d < end; d += gridDim.x * blockDim.x)
-        solve_row<DIAG>(d, cap, friction, row_a, row_b, row_count, row_normal, row_data, row_acc, inv_inertia, inertia_stride, vel);
+        solve_row<DIAG>(d, rows, friction, inv_inertia, inertia_stride, vel);
 }
 
 // The colour classes [first, n_colours) of one iteration in ONE launch of ONE workgroup: colours in
@@ -221,15 +216,11 @@ __global__ __launch_bounds__(256) void k_solve_color(const StepCounters* __restr
 // the body-velocity writes of one colour before the reads of the next). Same order of work as one launch per
 // colour, without paying a ~8 us launch for a few hundred manifolds. `first` is a host HINT (the small
 // colours of the previous step); any value gives the same result, only the speed changes.
-constexpr int kTailThreads = 512;  // 2 waves per SIMD: the row solve needs ~144 VGPRs, 1024 threads would spill
+constexpr int kTailThreads = 512;  // 2 waves per SIMD: the row solve needs >128 VGPRs, 1024 threads would spill
 template <bool DIAG>
-__global__ __launch_bounds__(kTailThreads) void k_solve_tail(const StepCounters* __restrict__ ctr, uint32_t first, uint64_t cap,
-                                                            float friction, const uint32_t* __restrict__ row_a,
-                                                            const uint32_t* __restrict__ row_b,
-                                                            const uint32_t* __restrict__ row_count,
-                                                            const float* __restrict__ row_normal,
-                                                            const float* __restrict__ row_data, float* __restrict__ row_acc,
-                                                            const float* __restrict__ inv_inertia, uint32_t inertia_stride, float* __restrict__ vel) {
+__global__ __launch_bounds__(kTailThreads) void k_solve_tail(const StepCounters* __restrict__ ctr, uint32_t first, RowArrays rows,
+                                                            float friction, const float* __restrict__ inv_inertia,
+                                                            uint32_t inertia_stride, float* __restrict__ vel) {
     if (ctr->overflow) return;
     const uint32_t last = ctr->n_colors;
     if (first >= last) return;
@@ -241,7 +232,7 @@ __global__ __launch_bounds__(kTailThreads) void k_solve_tail(const StepCounters*
     for (uint32_t col = first; col < last; ++col) {
         const uint32_t start = s_start[col], end = s_start[col + 1];
         for (uint32_t d = start + threadIdx.x; d < end; d += kTailThreads)
-            solve_row<DIAG>(d, cap, friction, row_a, row_b, row_count, row_normal, row_data, row_acc, inv_inertia, inertia_stride, vel);
+            solve_row<DIAG>(d, rows, friction, inv_inertia, inertia_stride, vel);
         __threadfence_block();
         __syncthreads();
     }
@@ -255,22 +246,23 @@ __global__ __launch_bounds__(kTailThreads) void k_solve_tail(const StepCounters*
 // only be made by the row holding ticket k for A (k = iteration * deg(A) + rank of the row's colour among A's
 // colours; k_rows_build). In-flight velocities live in `flow_vel` as two 16-byte granules {x, y, z, tag} whose
 // tag = (epoch << 16) | number of updates applied, i.e. THE DATA IS ITS OWN READY FLAG: a row polls its bodies'
-// granules (sc1 loads: bypass the CU's L1) until both tags equal its ticket, solves, and stores them back
+// granules (sc1 loads: served past the CU's L1) until both tags equal its ticket, solves, and stores them back
 // (sc1 = write-through stores) with tag + 1. One hop costs ~0.7-1.0 us (tools/hop_bench.hip) instead of a
 // launch, and rows of different colours / iterations overlap wherever the contact graph allows.
 //   * the FIRST update of a body reads the plain `vel` record (written by the previous kernel), the LAST one
 //     writes it (read by the next kernel): flow_vel never needs initialising; stale tags of earlier steps carry
 //     another epoch;
-//   * accumulated impulses cross iterations the same way ({pn, pt0, pt1, tag = iteration});
-//   * work items (iteration, chunk of 256*sub rows) are handed out by an atomic ticket in solve order, so every
+//   * accumulated impulses cross iterations the same way (row_acc {pn, pt0, pt1, tag = iteration});
+//   * work items (iteration, chunk of blockDim rows) are handed out by an atomic ticket in solve order, so every
 //     dependency of an item was taken EARLIER by a workgroup that is running: no co-residency assumption, no
 //     deadlock by construction; and every spin is bounded (timeout -> overflow bit 4 -> PHYS_ERR_HIP at sync).
 // Granule discipline follows the guide's data-tagged hand-off: each granule is written by ONE 16-byte sc1
-// store and only ever read by 16-byte sc1 loads.
+// store and only ever read by 16-byte sc1 loads. Waiting waves cost issue slots and L2 bandwidth, so the launch
+// is sized to about one wave per SIMD (launch_solver) and waiters back off by their distance in hops.
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ u32x4 ld_granule(__amdgpu_buffer_rsrc_t r, uint32_t byte_off) {
-    // aux: 16 = sc1 (served past the CU's L1), bit 31 = volatile (the compiler must re-issue it in every sweep)
+    // aux: 16 = sc1, bit 31 = volatile (the compiler must re-issue the load in every sweep)
     return __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, (int)0x80000010);
 }
 __device__ __forceinline__ void st_granule(__amdgpu_buffer_rsrc_t r, uint32_t byte_off, v3 v, uint32_t tag) {
@@ -278,30 +270,28 @@ __device__ __forceinline__ void st_granule(__amdgpu_buffer_rsrc_t r, uint32_t by
     g.x = __float_as_uint(v.x); g.y = __float_as_uint(v.y); g.z = __float_as_uint(v.z); g.w = tag;
     __builtin_amdgcn_raw_buffer_store_b128(g, r, byte_off, 0, 16);
 }
+__device__ __forceinline__ v3 granule_v3(u32x4 g) {
+    return v3_make(__uint_as_float(g.x), __uint_as_float(g.y), __uint_as_float(g.z));
+}
 
-constexpr uint32_t kFlowTimeoutTicks = 300000000u;  // 3 s of the 100 MHz wall clock
+constexpr long long kFlowTimeoutTicks = 300000000ll;  // 3 s of the 100 MHz wall clock
+constexpr uint64_t kFlowMaxManifolds = 400000;        // above: one launch per colour streams better
 
 template <bool DIAG>
-__global__ __launch_bounds__(256) void k_solve_flow(StepCounters* __restrict__ ctr, uint32_t iterations, uint32_t sub,
-                                                    uint32_t epoch, uint64_t cap, float friction,
-                                                    const uint32_t* __restrict__ row_a, const uint32_t* __restrict__ row_b,
-                                                    const uint32_t* __restrict__ row_count,
-                                                    const uint32_t* __restrict__ row_ticket,
-                                                    const float* __restrict__ row_normal,
-                                                    const float* __restrict__ row_data,
+__global__ __launch_bounds__(256) void k_solve_flow(StepCounters* __restrict__ ctr, uint32_t iterations, uint32_t epoch,
+                                                    RowArrays rows, float friction,
                                                     const float* __restrict__ inv_inertia, uint32_t inertia_stride,
-                                                    float* vel, float* flow_vel, uint32_t n_bodies, float* flow_acc,
-                                                    uint32_t sleep_mid, uint32_t sleep_far) {
+                                                    float* vel, float* flow_vel, uint32_t n_bodies) {
     __shared__ uint32_t s_item;
     if (ctr->overflow) return;
     const uint32_t M = ctr->n_manifolds;
-    const uint32_t rows_per_item = blockDim.x * sub;
-    const uint32_t nchunks = (M + rows_per_item - 1) / rows_per_item;
+    const uint32_t nchunks = (M + blockDim.x - 1) / blockDim.x;
     const uint32_t total = nchunks * iterations;
+    const uint32_t cap = (uint32_t)rows.cap;  // collision_alloc: 64 * cap < 4 GiB (32-bit buffer offsets)
     const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(flow_vel, 0, n_bodies * 32u, 0x00020000);
-    // flow_acc can exceed 4 GiB: a window of this item's rows is described per item below
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(rows.acc, 0, cap * 64u, 0x00020000);
     const uint32_t etag = epoch << 16;
-    const unsigned long long t_start = wall_clock64();
+    const long long t_start = wall_clock64();
     for (;;) {
         __syncthreads();
         if (threadIdx.x == 0)
@@ -312,113 +302,110 @@ __global__ __launch_bounds__(256) void k_solve_flow(StepCounters* __restrict__ c
         if (L >= total) return;
         const uint32_t it = L / nchunks, chunk = L - it * nchunks;
         const bool last_it = it + 1 == iterations;
-        const uint32_t item_first = chunk * rows_per_item;
-        const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(flow_acc + 16 * (size_t)item_first, 0,
-                                                                              rows_per_item * 64u, 0x00020000);
-        for (uint32_t sc = 0; sc < sub; ++sc) {
-            const uint32_t local = sc * blockDim.x + threadIdx.x;
-            const uint32_t d = item_first + local;
-            bool done = d >= M;
-            RowRegs R;
-            uint32_t tA = 0, tB = 0;
-            bool finalA = false, finalB = false;
-            m33 IA, IB;
-            float ima = 0.0f, imb = 0.0f;
-            v3 vA = v3_make(0.0f, 0.0f, 0.0f), wA = vA, vB = vA, wB = vA;
-            float massA = 0.0f, massB = 0.0f;
+        const uint32_t d = chunk * blockDim.x + threadIdx.x;
+        bool done = d >= M;
+        RowRegs R;
+        uint32_t tA = 0, tB = 0;
+        bool finalA = false, finalB = false;
+        m33 IA, IB;
+        float ima = 0.0f, imb = 0.0f, massA = 0.0f, massB = 0.0f;
+        v3 vA = v3_make(0.0f, 0.0f, 0.0f), wA = vA, vB = vA, wB = vA;
 #pragma unroll
-            for (int k = 0; k < 9; ++k) { IA.m[k] = 0.0f; IB.m[k] = 0.0f; }
-            R.a = 0; R.b = PHYS_GROUND_ID; R.sm.count = 0; R.sm.has_b = 0;
-            if (!done) {
-                // everything that is constant during the solve: plain loads, in flight while the row waits
-                load_row(R, d, cap, row_a, row_b, row_count, row_normal, row_data, nullptr);
-                const uint32_t tk = row_ticket[d];
-                const uint32_t rankA = tk & 0xFFu, degA = (tk >> 8) & 0xFFu, rankB = (tk >> 16) & 0xFFu, degB = tk >> 24;
-                tA = it * degA + rankA;
-                finalA = last_it && rankA + 1 == degA;
-                IA = ld_inertia<DIAG>(inv_inertia, R.a * inertia_stride);
-                const BodyVel A0 = ld_vel(vel, R.a);  // v, w valid only for ticket 0; the masses always
-                ima = A0.inv_mass; massA = A0.mass; vA = A0.v; wA = A0.w;
-                if (R.sm.has_b) {
-                    tB = it * degB + rankB;
-                    finalB = last_it && rankB + 1 == degB;
-                    IB = ld_inertia<DIAG>(inv_inertia, R.b * inertia_stride);
-                    const BodyVel B0 = ld_vel(vel, R.b);
-                    imb = B0.inv_mass; massB = B0.mass; vB = B0.v; wB = B0.w;
-                }
+        for (int k = 0; k < 9; ++k) { IA.m[k] = 0.0f; IB.m[k] = 0.0f; }
+        R.a = 0; R.b = PHYS_GROUND_ID; R.sm.count = 0; R.sm.has_b = 0;
+        if (!done) {
+            // everything that is constant during the solve: plain loads, in flight while the row waits
+            load_row<false>(R, d, rows);
+            const uint32_t rankA = R.ticket & 0xFFu, degA = (R.ticket >> 8) & 0xFFu;
+            const uint32_t rankB = (R.ticket >> 16) & 0xFFu, degB = R.ticket >> 24;
+            tA = it * degA + rankA;
+            finalA = last_it && rankA + 1 == degA;
+            IA = ld_inertia<DIAG>(inv_inertia, R.a * inertia_stride);
+            const BodyVel A0 = ld_vel(vel, R.a);  // v, w are the body's state only for ticket 0; the masses always
+            ima = A0.inv_mass; massA = A0.mass; vA = A0.v; wA = A0.w;
+            if (R.sm.has_b) {
+                tB = it * degB + rankB;
+                finalB = last_it && rankB + 1 == degB;
+                IB = ld_inertia<DIAG>(inv_inertia, R.b * inertia_stride);
+                const BodyVel B0 = ld_vel(vel, R.b);
+                imb = B0.inv_mass; massB = B0.mass; vB = B0.v; wB = B0.w;
             }
-            const bool needA = tA != 0, needB = R.sm.has_b && tB != 0, needAcc = it != 0;
-            uint32_t sweeps = 0;
-            for (;;) {
-                uint32_t gap = 0;
-                if (!done) {
-                    u32x4 a0, a1, b0, b1, p[4];
-                    if (needA) { a0 = ld_granule(rv, R.a * 32u); a1 = ld_granule(rv, R.a * 32u + 16u); }
-                    if (needB) { b0 = ld_granule(rv, R.b * 32u); b1 = ld_granule(rv, R.b * 32u + 16u); }
-                    if (needAcc) {
+        }
+        // what is still missing (a matched granule cannot change any more: this row is its next writer)
+        bool needA = !done && tA != 0, needB = !done && R.sm.has_b && tB != 0, needAcc = !done && it != 0;
+        uint32_t sweeps = 0;
+        for (;;) {
+            uint32_t gap = 0;
+            if (!done) {
+                u32x4 a0, a1, b0, b1, p[4];
+                if (needA) { a0 = ld_granule(rv, R.a * 32u); a1 = ld_granule(rv, R.a * 32u + 16u); }
+                if (needB) { b0 = ld_granule(rv, R.b * 32u); b1 = ld_granule(rv, R.b * 32u + 16u); }
+                if (needAcc) {
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) if (k < R.sm.count) p[k] = ld_granule(ra, local * 64u + 16u * k);
-                    }
-                    bool ok = true;
-                    if (needA) {
-                        const uint32_t want = etag | tA;
-                        ok = ok && a0.w == want && a1.w == want;
+                    for (int k = 0; k < 4; ++k) if (k < R.sm.count) p[k] = ld_granule(ra, (k * cap + d) * 16u);
+                }
+                if (needA) {
+                    const uint32_t want = etag | tA;
+                    if (a0.w == want && a1.w == want) { vA = granule_v3(a0); wA = granule_v3(a1); needA = false; }
+                    else {
                         const uint32_t seen = (a0.w >> 16) == epoch ? (a0.w & 0xFFFFu) : 0u;
                         gap = tA > seen ? tA - seen : 1u;
                     }
-                    if (needB) {
-                        const uint32_t want = etag | tB;
-                        ok = ok && b0.w == want && b1.w == want;
+                }
+                if (needB) {
+                    const uint32_t want = etag | tB;
+                    if (b0.w == want && b1.w == want) { vB = granule_v3(b0); wB = granule_v3(b1); needB = false; }
+                    else {
                         const uint32_t seen = (b0.w >> 16) == epoch ? (b0.w & 0xFFFFu) : 0u;
                         const uint32_t g = tB > seen ? tB - seen : 1u;
                         gap = g > gap ? g : gap;
                     }
-                    if (needAcc) {
+                }
+                if (needAcc) {
+                    bool all = true;
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) if (k < R.sm.count) ok = ok && p[k].w == (etag | it);
-                    }
-                    if (ok) {
-                        if (needA) { vA = v3_make(__uint_as_float(a0.x), __uint_as_float(a0.y), __uint_as_float(a0.z));
-                                     wA = v3_make(__uint_as_float(a1.x), __uint_as_float(a1.y), __uint_as_float(a1.z)); }
-                        if (needB) { vB = v3_make(__uint_as_float(b0.x), __uint_as_float(b0.y), __uint_as_float(b0.z));
-                                     wB = v3_make(__uint_as_float(b1.x), __uint_as_float(b1.y), __uint_as_float(b1.z)); }
-                        if (needAcc) {
+                    for (int k = 0; k < 4; ++k) if (k < R.sm.count) all = all && p[k].w == (etag | it);
+                    if (all) {
 #pragma unroll
-                            for (int k = 0; k < 4; ++k) if (k < R.sm.count) {
-                                R.sm.row[k].pn = __uint_as_float(p[k].x);
-                                R.sm.row[k].pt[0] = __uint_as_float(p[k].y);
-                                R.sm.row[k].pt[1] = __uint_as_float(p[k].z);
-                            }
+                        for (int k = 0; k < 4; ++k) if (k < R.sm.count) {
+                            R.sm.row[k].pn = __uint_as_float(p[k].x);
+                            R.sm.row[k].pt[0] = __uint_as_float(p[k].y);
+                            R.sm.row[k].pt[1] = __uint_as_float(p[k].z);
                         }
-                        solve_manifold(&R.sm, friction, ima, &IA, imb, &IB, &vA, &wA, &vB, &wB);
-                        // publish: bodies first (they are what other rows wait for)
-                        if (finalA) { BodyVel o; o.v = vA; o.inv_mass = ima; o.w = wA; o.mass = massA; st_vel(vel, R.a, o); }
-                        else { st_granule(rv, R.a * 32u, vA, etag | (tA + 1u)); st_granule(rv, R.a * 32u + 16u, wA, etag | (tA + 1u)); }
-                        if (R.sm.has_b) {
-                            if (finalB) { BodyVel o; o.v = vB; o.inv_mass = imb; o.w = wB; o.mass = massB; st_vel(vel, R.b, o); }
-                            else { st_granule(rv, R.b * 32u, vB, etag | (tB + 1u)); st_granule(rv, R.b * 32u + 16u, wB, etag | (tB + 1u)); }
-                        }
-                        if (!last_it) {
-#pragma unroll
-                            for (int k = 0; k < 4; ++k) if (k < R.sm.count)
-                                st_granule(ra, local * 64u + 16u * k,
-                                           v3_make(R.sm.row[k].pn, R.sm.row[k].pt[0], R.sm.row[k].pt[1]), etag | (it + 1u));
-                        }
-                        done = true;
+                        needAcc = false;
+                    } else if (gap == 0) {
+                        gap = 1;
                     }
                 }
-                if (__all(done)) break;
-                // back off in proportion to how many hops away the nearest waiting lane is
-                if (__any(!done && gap <= 1u)) __builtin_amdgcn_s_sleep(1);
-                else if (__any(!done && gap <= 4u)) { for (uint32_t q = 0; q < sleep_mid; ++q) __builtin_amdgcn_s_sleep(8); }
-                else { for (uint32_t q = 0; q < sleep_far; ++q) __builtin_amdgcn_s_sleep(8); }
-                if ((++sweeps & 63u) == 0u) {
-                    const bool dead = (wall_clock64() - t_start > kFlowTimeoutTicks) ||
-                                      (__hip_atomic_load(&ctr->overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 16u);
-                    if (dead) {  // wave-uniform: both inputs are
-                        if ((threadIdx.x & 63u) == 0u) atomicOr(&ctr->overflow, 16u);
-                        done = true;
+                if (!needA && !needB && !needAcc) {
+                    solve_manifold(&R.sm, friction, ima, &IA, imb, &IB, &vA, &wA, &vB, &wB);
+                    // publish: bodies first (they are what other rows wait for)
+                    if (finalA) { BodyVel o; o.v = vA; o.inv_mass = ima; o.w = wA; o.mass = massA; st_vel(vel, R.a, o); }
+                    else { st_granule(rv, R.a * 32u, vA, etag | (tA + 1u)); st_granule(rv, R.a * 32u + 16u, wA, etag | (tA + 1u)); }
+                    if (R.sm.has_b) {
+                        if (finalB) { BodyVel o; o.v = vB; o.inv_mass = imb; o.w = wB; o.mass = massB; st_vel(vel, R.b, o); }
+                        else { st_granule(rv, R.b * 32u, vB, etag | (tB + 1u)); st_granule(rv, R.b * 32u + 16u, wB, etag | (tB + 1u)); }
                     }
+                    if (!last_it) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) if (k < R.sm.count)
+                            st_granule(ra, (k * cap + d) * 16u, v3_make(R.sm.row[k].pn, R.sm.row[k].pt[0], R.sm.row[k].pt[1]),
+                                       etag | (it + 1u));
+                    }
+                    done = true;
+                }
+            }
+            if (__all(done)) break;
+            // back off in proportion to how many hops away the nearest waiting lane is
+            if (__any(!done && gap <= 1u)) __builtin_amdgcn_s_sleep(1);
+            else if (__any(!done && gap <= 4u)) __builtin_amdgcn_s_sleep(40);
+            else __builtin_amdgcn_s_sleep(127);
+            if ((++sweeps & 63u) == 0u) {
+                const bool dead = (wall_clock64() - t_start > kFlowTimeoutTicks) ||
+                                  (__hip_atomic_load(&ctr->overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 16u);
+                if (dead) {  // wave-uniform: both inputs are
+                    if ((threadIdx.x & 63u) == 0u) atomicOr(&ctr->overflow, 16u);
+                    done = true;
                 }
             }
         }
@@ -441,7 +428,15 @@ void launch_solver(phys_world* w, float dt) {
     const dim3 tb(256);
     const bool diag = w->all_diag_inertia;
     // every body shares one diagonal tensor (the reference's only case, identity): all lanes read entry 0
-    const uint32_t istride = w->uniform_inertia ? 0u : 1u;
+    const float* inertia = diag ? w->inv_inertia_diag.p : w->inv_inertia.p;
+    const uint32_t stride = diag && w->uniform_inertia ? 0u : 1u;
+    RowArrays rows;
+    rows.hdr = reinterpret_cast<uint4*>(w->row_hdr.p);
+    rows.n = reinterpret_cast<float4*>(w->row_n.p);
+    rows.pt = reinterpret_cast<float4*>(w->row_pt.p);
+    rows.tb = reinterpret_cast<float4*>(w->row_tb.p);
+    rows.acc = reinterpret_cast<float4*>(w->row_acc.p);
+    rows.cap = cap;
     auto grid_for_count = [&](uint64_t count) {
         uint64_t b = (count * 5 / 4 + 255) / 256 + 1;
         const uint64_t hi = (cap + 255) / 256;
@@ -453,41 +448,28 @@ void launch_solver(phys_world* w, float dt) {
     // the dataflow kernel wins while a colour class is too small to fill the chip (launch / latency bound);
     // beyond that the per-colour launches stream better. Both give the same bits, so the choice may change
     // from step to step.
-    const bool flow = !(w->cfg.flags & PHYS_FLAG_SOLVER_PER_COLOR) && h.valid && m_hint <= 400000;
-    { PHYS_PROF(w, PHYS_STAGE_ROWS); hipLaunchKernelGGL(k_rows_build, grid_for_count(m_hint), tb, 0, s, w->counters.p, cap, sp, w->row_src.p, w->man_a.p, w->man_b.p, w->man_count.p,
-                       w->man_normal.p, w->man_points.p, w->pos.p, w->vel.p, w->inv_inertia.p, w->row_a.p,
-                       w->row_b.p, w->row_count.p, w->row_normal.p, w->row_data.p, w->row_acc.p, w->man_color.p,
-                       w->color_state.p, flow ? w->row_ticket.p : nullptr); }
+    const bool flow = w->flow_vel.p && h.valid && m_hint <= kFlowMaxManifolds && w->cfg.solver_iterations > 0;
+    { PHYS_PROF(w, PHYS_STAGE_ROWS); hipLaunchKernelGGL(k_rows_build, grid_for_count(m_hint), tb, 0, s, w->counters.p, rows, sp, w->row_src.p, w->man_a.p, w->man_b.p, w->man_count.p,
+                       w->man_normal.p, w->man_points.p, w->pos.p, w->vel.p, w->inv_inertia.p, w->man_color.p,
+                       w->color_state.p, flow ? 1 : 0); }
     if (flow) {
-        if (w->cfg.solver_iterations == 0) return;
         if (++w->flow_epoch > 0xFFFFu) {  // tags would repeat: forget every old one
             (void)hipMemsetAsync(w->flow_vel.p, 0, 8 * w->n * sizeof(float), s);
-            (void)hipMemsetAsync(w->flow_acc.p, 0, 16 * cap * sizeof(float), s);
+            (void)hipMemsetAsync(w->row_acc.p, 0, 16 * cap * sizeof(float), s);
             w->flow_epoch = 1;
         }
-        static const uint32_t k_sub = getenv("PHYS_FLOW_SUB") ? atoi(getenv("PHYS_FLOW_SUB")) : 0;
-        static const uint32_t k_mid = getenv("PHYS_FLOW_MID") ? atoi(getenv("PHYS_FLOW_MID")) : 5;
-        static const uint32_t k_far = getenv("PHYS_FLOW_FAR") ? atoi(getenv("PHYS_FLOW_FAR")) : 32;
-        static const uint32_t e_grid = getenv("PHYS_FLOW_GRID") ? atoi(getenv("PHYS_FLOW_GRID")) : 0;
-        static const uint32_t e_threads = getenv("PHYS_FLOW_THREADS") ? atoi(getenv("PHYS_FLOW_THREADS")) : 0;
         // about one wave per SIMD or less: waiting waves must not crowd out the ones that can run
-        const uint32_t k_threads = e_threads ? e_threads : (m_hint <= 20000 ? 64u : 256u);
-        const uint32_t k_grid = e_grid ? e_grid : (k_threads == 64 ? 192u : 256u);
-        const dim3 ftb(k_threads);
-        const uint32_t sub = k_sub ? k_sub : 1u;
-        uint64_t items = (uint64_t)w->cfg.solver_iterations * ((m_hint * 5 / 4 + k_threads * sub - 1) / (k_threads * sub)) + 1;
-        if (items > k_grid) items = k_grid;  // more than can be resident: the rest of the items are taken by the same workgroups
+        const uint32_t threads = m_hint <= 20000 ? 64u : 256u;
+        uint64_t items = (uint64_t)w->cfg.solver_iterations * ((m_hint * 5 / 4 + threads - 1) / threads) + 1;
+        const uint64_t most = threads == 64 ? 192 : 256;
+        if (items > most) items = most;  // the remaining items are taken by the same workgroups
         PHYS_PROF(w, PHYS_STAGE_SOLVE_FLOW);
         if (diag)
-            hipLaunchKernelGGL(k_solve_flow<true>, dim3((unsigned)items), ftb, 0, s, w->counters.p, w->cfg.solver_iterations, sub,
-                               w->flow_epoch, cap, sp.friction, w->row_a.p, w->row_b.p, w->row_count.p, w->row_ticket.p,
-                               w->row_normal.p, w->row_data.p, w->inv_inertia_diag.p, istride, w->vel.p, w->flow_vel.p,
-                               (uint32_t)w->n, w->flow_acc.p, k_mid, k_far);
+            hipLaunchKernelGGL(k_solve_flow<true>, dim3((unsigned)items), dim3(threads), 0, s, w->counters.p, w->cfg.solver_iterations,
+                               w->flow_epoch, rows, sp.friction, inertia, stride, w->vel.p, w->flow_vel.p, (uint32_t)w->n);
         else
-            hipLaunchKernelGGL(k_solve_flow<false>, dim3((unsigned)items), ftb, 0, s, w->counters.p, w->cfg.solver_iterations, sub,
-                               w->flow_epoch, cap, sp.friction, w->row_a.p, w->row_b.p, w->row_count.p, w->row_ticket.p,
-                               w->row_normal.p, w->row_data.p, w->inv_inertia.p, 1u, w->vel.p, w->flow_vel.p,
-                               (uint32_t)w->n, w->flow_acc.p, k_mid, k_far);
+            hipLaunchKernelGGL(k_solve_flow<false>, dim3((unsigned)items), dim3(threads), 0, s, w->counters.p, w->cfg.solver_iterations,
+                               w->flow_epoch, rows, sp.friction, inertia, stride, w->vel.p, w->flow_vel.p, (uint32_t)w->n);
         return;
     }
     // colours [0, big) get a launch each; [big, n_colours) go through the single-workgroup tail
@@ -502,23 +484,19 @@ void launch_solver(phys_world* w, float dt) {
         for (uint32_t col = 0; col < big; ++col) {
             PHYS_PROF(w, PHYS_STAGE_SOLVE);
             if (diag)
-                hipLaunchKernelGGL(k_solve_color<true>, grid_for_count(h.color_count[col]), tb, 0, s, w->counters.p, col, cap, sp.friction,
-                                   w->row_a.p, w->row_b.p, w->row_count.p, w->row_normal.p, w->row_data.p, w->row_acc.p,
-                                   w->inv_inertia_diag.p, istride, w->vel.p);
+                hipLaunchKernelGGL(k_solve_color<true>, grid_for_count(h.color_count[col]), tb, 0, s, w->counters.p, col, rows,
+                                   sp.friction, inertia, stride, w->vel.p);
             else
-                hipLaunchKernelGGL(k_solve_color<false>, grid_for_count(h.color_count[col]), tb, 0, s, w->counters.p, col, cap, sp.friction,
-                                   w->row_a.p, w->row_b.p, w->row_count.p, w->row_normal.p, w->row_data.p, w->row_acc.p,
-                                   w->inv_inertia.p, 1u, w->vel.p);
+                hipLaunchKernelGGL(k_solve_color<false>, grid_for_count(h.color_count[col]), tb, 0, s, w->counters.p, col, rows,
+                                   sp.friction, inertia, stride, w->vel.p);
         }
         PHYS_PROF(w, PHYS_STAGE_SOLVE_TAIL);
         if (diag)
-            hipLaunchKernelGGL(k_solve_tail<true>, dim3(1), dim3(kTailThreads), 0, s, w->counters.p, big, cap, sp.friction,
-                               w->row_a.p, w->row_b.p, w->row_count.p, w->row_normal.p, w->row_data.p, w->row_acc.p,
-                               w->inv_inertia_diag.p, istride, w->vel.p);
+            hipLaunchKernelGGL(k_solve_tail<true>, dim3(1), dim3(kTailThreads), 0, s, w->counters.p, big, rows, sp.friction,
+                               inertia, stride, w->vel.p);
         else
-            hipLaunchKernelGGL(k_solve_tail<false>, dim3(1), dim3(kTailThreads), 0, s, w->counters.p, big, cap, sp.friction,
-                               w->row_a.p, w->row_b.p, w->row_count.p, w->row_normal.p, w->row_data.p, w->row_acc.p,
-                               w->inv_inertia.p, 1u, w->vel.p);
+            hipLaunchKernelGGL(k_solve_tail<false>, dim3(1), dim3(kTailThreads), 0, s, w->counters.p, big, rows, sp.friction,
+                               inertia, stride, w->vel.p);
     }
 }
 

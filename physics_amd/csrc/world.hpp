@@ -196,18 +196,18 @@ struct phys_world {
     phys::DevBuf<uint32_t> color_block_hist;  // [colour][workgroup] histogram / offsets of the colour sort
     // colouring state
     phys::DevBuf<unsigned long long> color_state;  // 4n: used masks | three rotating per-body priority buffers
-    // solver rows, colour-sorted SoA
-    phys::DevBuf<uint32_t> row_a, row_b, row_count, row_src;
-    phys::DevBuf<float> row_normal;  // 3 per manifold (SoA planes)
-    phys::DevBuf<float> row_data;    // per point-slot planes: rA(3) rB(3) nmass tmass0 tmass1 bias
-    phys::DevBuf<float> row_acc;     // per point-slot planes: pn pt0 pt1
-    // single-launch dataflow solver (k_solve_flow): in-flight body velocities and accumulated impulses travel
-    // between workgroups as 16-byte granules {x, y, z, tag} (the tag says WHICH update of that body / row the
-    // data is, so the data is its own ready flag)
-    phys::DevBuf<uint32_t> row_ticket;  // per row: rank of the row among body A's / B's manifolds and their counts
-    phys::DevBuf<float> flow_vel;       // 8 per body: {v.xyz, tag} {w.xyz, tag}
-    phys::DevBuf<float> flow_acc;       // 16 per manifold row: 4 x {pn, pt0, pt1, tag}
-    uint32_t flow_epoch = 0;            // solves since the buffers were cleared (upper half of every tag)
+    // solver rows, colour-major, plane-major arrays of 16-byte elements (layout: solver.hip)
+    phys::DevBuf<uint32_t> row_src;  // row -> manifold (the colour sort)
+    phys::DevBuf<uint32_t> row_hdr;  // 4 per row: body a, body b, point count, update tickets
+    phys::DevBuf<float> row_n;       // 4 per row
+    phys::DevBuf<float> row_pt;      // 8 planes of float4
+    phys::DevBuf<float> row_tb;      // 2 planes of float4
+    phys::DevBuf<float> row_acc;     // 4 planes of float4 {pn, pt0, pt1, tag}
+    // single-launch dataflow solver (k_solve_flow): in-flight body velocities travel between workgroups as
+    // 16-byte granules {x, y, z, tag} (the tag says WHICH update of that body the data is: the data is its own
+    // ready flag)
+    phys::DevBuf<float> flow_vel;    // 8 per body: {v.xyz, tag} {w.xyz, tag}; null = per-colour launches only
+    uint32_t flow_epoch = 0;         // solves since the buffers were cleared (upper half of every tag)
     // multi-GPU halo
     phys::DevBuf<uint32_t> cross_pairs;
     uint64_t max_cross_pairs = 0;
