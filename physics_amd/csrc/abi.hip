@@ -18,8 +18,10 @@ using namespace phys;
 
 namespace phys {
 void poll_snapshots(phys_world* w);
-// enqueue an asynchronous copy of the step counters into the next pinned ring slot
-void snapshot_counters_async(phys_world* w) {
+// Launch-size hints: snapshots of the step counters in a ring of pinned host slots. A slot is filled either by
+// an asynchronous copy (snapshot_counters_async) or by a kernel writing the host-mapped slot itself
+// (snapshot_acquire -> kernel -> snapshot_commit); an event behind it tells poll_snapshots when it is complete.
+StepCounters* snapshot_acquire(phys_world* w) {
     const uint32_t k = w->snap_next;
     if (w->snap_pending[k]) {
         // ring full: the host is kSnapRing steps ahead of the device. Wait for the oldest sample, so the
@@ -28,14 +30,23 @@ void snapshot_counters_async(phys_world* w) {
         poll_snapshots(w);
     }
     if (!w->h_snap[k]) {
-        if (hipHostMalloc((void**)&w->h_snap[k], sizeof(StepCounters), hipHostMallocDefault) != hipSuccess) return;
-        if (hipEventCreateWithFlags(&w->snap_event[k], hipEventDisableTiming) != hipSuccess) return;
+        if (hipHostMalloc((void**)&w->h_snap[k], sizeof(StepCounters), hipHostMallocDefault) != hipSuccess) return nullptr;
+        if (hipEventCreateWithFlags(&w->snap_event[k], hipEventDisableTiming) != hipSuccess) return nullptr;
     }
-    (void)hipMemcpyAsync(w->h_snap[k], w->counters.p, sizeof(StepCounters), hipMemcpyDeviceToHost, w->stream);
+    return w->h_snap[k];
+}
+void snapshot_commit(phys_world* w) {
+    const uint32_t k = w->snap_next;
     (void)hipEventRecord(w->snap_event[k], w->stream);
     w->snap_pending[k] = true;
     w->snap_full[k] = w->snap_tag_full;  // was this update a full re-colouring?
     w->snap_next = (k + 1) % phys_world::kSnapRing;
+}
+void snapshot_counters_async(phys_world* w) {
+    StepCounters* slot = snapshot_acquire(w);
+    if (!slot) return;
+    (void)hipMemcpyAsync(slot, w->counters.p, sizeof(StepCounters), hipMemcpyDeviceToHost, w->stream);
+    snapshot_commit(w);
 }
 
 // adopt every snapshot whose copy has completed (oldest first, so the newest complete one wins)
@@ -321,8 +332,11 @@ static int32_t enqueue_update(phys_world* w, float dt) {
     if (!collisions) {
         launch_step_full(w, dt, gravity_pending);
     } else {
-        zero_step_state(w, /*including_extent=*/w->steps % 32 == 0);
-        launch_step_velocity_aabb(w, dt, gravity_pending);
+        // per-step state: zeroed by the first kernel of the step itself; every 32nd step a memset in front of it
+        // also restarts the running extent bound (which that kernel raises, so it cannot zero it)
+        const bool restart_extent = w->steps % 32 == 0 || w->step_zero_reset_bytes % 16 != 0 || (w->step_zero_reset_bytes >> 36) != 0;
+        if (restart_extent) zero_step_state(w, /*including_extent=*/true);
+        launch_step_velocity_aabb(w, dt, gravity_pending, /*zero_step=*/!restart_extent);
         launch_broadphase(w);
         if (!(w->cfg.flags & PHYS_FLAG_BROADPHASE_ONLY)) {
             launch_narrowphase(w);

@@ -158,6 +158,81 @@ __global__ __launch_bounds__(256) void k_scatter(uint32_t n, const float* __rest
     st3(sorted_box, 2 * s + 1, ld3(aabb, 2 * i + 1));
 }
 
+// ---- small scenes: the whole grid build in ONE workgroup ------------------------------------------
+// cell assignment, scan of the bucket counts and the scatter as three phases of one launch (barriers instead of
+// four kernel boundaries of ~6 us each). Bucket and rank of a body stay in registers between the phases.
+constexpr int kGridSmallThreads = 1024;
+constexpr int kGridSmallBodies = 2;      // per thread: n <= 2048 (above, one workgroup is slower than the five launches)
+constexpr int kGridSmallBuckets = 4;     // per thread: T <= 4096
+__global__ __launch_bounds__(kGridSmallThreads) void k_grid_small(uint32_t n, const float* __restrict__ aabb,
+                                                                  const uint32_t* __restrict__ shape,
+                                                                  const StepCounters* __restrict__ ctr, uint32_t axis_mask,
+                                                                  uint32_t T, uint32_t* bucket_count, uint32_t* bucket_start,
+                                                                  uint32_t* __restrict__ sorted_ids,
+                                                                  float* __restrict__ sorted_box) {
+    __shared__ uint32_t wtot[kGridSmallThreads / 64];
+    const float inv_cell = grid_inv_cell(ctr);
+    uint32_t bk[kGridSmallBodies], rk[kGridSmallBodies];
+#pragma unroll
+    for (int k = 0; k < kGridSmallBodies; ++k) {
+        const uint32_t i = k * kGridSmallThreads + threadIdx.x;
+        bk[k] = kInvalid; rk[k] = 0;
+        if (i < n && shape[i] != PHYS_SPEC_SHAPE_NONE) {
+            const v3 lo = ld3(aabb, 2 * i), hi = ld3(aabb, 2 * i + 1);
+            const int cx = cell_coord(0.5f * (lo.x + hi.x), inv_cell);
+            const int cy = cell_coord(0.5f * (lo.y + hi.y), inv_cell);
+            const int cz = cell_coord(0.5f * (lo.z + hi.z), inv_cell);
+            bk[k] = bucket_of_cell(cx, cy, cz, axis_mask);
+            rk[k] = atomicAdd(&bucket_count[bk[k]], 1u);  // order inside a bucket is irrelevant downstream
+        }
+    }
+    __threadfence();
+    __syncthreads();
+    // exclusive scan of the T counts: kGridSmallBuckets consecutive entries per thread (first touch of these
+    // lines by this CU: the loads see the atomics, which were performed at the L2)
+    const uint32_t base = threadIdx.x * kGridSmallBuckets;
+    uint32_t v[kGridSmallBuckets];
+    uint32_t sum = 0;
+#pragma unroll
+    for (int k = 0; k < kGridSmallBuckets; k += 4) {
+        uint4 q = make_uint4(0u, 0u, 0u, 0u);
+        if (base + k < T) q = *reinterpret_cast<const uint4*>(bucket_count + base + k);  // T is a multiple of 8
+        v[k] = q.x; v[k + 1] = q.y; v[k + 2] = q.z; v[k + 3] = q.w;
+        sum += q.x + q.y + q.z + q.w;
+    }
+    const uint32_t inc = wave_inclusive_scan(sum);
+    if ((threadIdx.x & 63) == 63) wtot[threadIdx.x >> 6] = inc;
+    __syncthreads();
+    uint32_t run = inc - sum;
+    for (uint32_t k = 0; k < (threadIdx.x >> 6); ++k) run += wtot[k];
+#pragma unroll
+    for (int k = 0; k < kGridSmallBuckets; k += 4) {
+        if (base + k < T) {
+            uint4 q;
+            q.x = run; q.y = run + v[k]; q.z = q.y + v[k + 1]; q.w = q.z + v[k + 2];
+            *reinterpret_cast<uint4*>(bucket_start + base + k) = q;
+            run = q.w + v[k + 3];
+        }
+    }
+    if (threadIdx.x == kGridSmallThreads - 1) {
+        uint32_t total = 0;
+        for (int k = 0; k < kGridSmallThreads / 64; ++k) total += wtot[k];
+        bucket_start[T] = total;  // grand total in the extra slot
+    }
+    __threadfence();
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kGridSmallBodies; ++k) {
+        if (bk[k] != kInvalid) {
+            const uint32_t i = k * kGridSmallThreads + threadIdx.x;
+            const uint32_t s = __hip_atomic_load(&bucket_start[bk[k]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + rk[k];
+            sorted_ids[s] = i;
+            st3(sorted_box, 2 * s, ld3(aabb, 2 * i));
+            st3(sorted_box, 2 * s + 1, ld3(aabb, 2 * i + 1));
+        }
+    }
+}
+
 // ---- candidate pairs ------------------------------------------------------------------------------
 constexpr int kPairThreads = 256;
 constexpr int kStagePerWave = 512;  // pairs staged in LDS per wave before a flush (4 KiB)
@@ -362,6 +437,11 @@ void launch_broadphase(phys_world* w) {
     const uint32_t axis_mask = (1u << bits) - 1u;
     hipStream_t s = w->stream;
     const dim3 gb((n + 255) / 256), tb(256);
+    if (n <= (uint32_t)(kGridSmallBodies * kGridSmallThreads) && T <= (uint32_t)(kGridSmallBuckets * kGridSmallThreads) && T % 8 == 0) {
+        PHYS_PROF(w, PHYS_STAGE_GRID);
+        hipLaunchKernelGGL(k_grid_small, dim3(1), dim3(kGridSmallThreads), 0, s, n, w->aabb.p, w->shape.p, w->counters.p, axis_mask, T,
+                           w->bucket_count.p, w->bucket_start.p, w->sorted_ids.p, w->sorted_box.p);
+    } else {
     { PHYS_PROF(w, PHYS_STAGE_GRID); hipLaunchKernelGGL(k_cell_assign, gb, tb, 0, s, n, w->aabb.p, w->shape.p, w->counters.p, axis_mask, w->bucket_of.p,
                        w->bucket_cursor.p, w->bucket_count.p); }
     {
@@ -373,6 +453,7 @@ void launch_broadphase(phys_world* w) {
     }
     { PHYS_PROF(w, PHYS_STAGE_GRID); hipLaunchKernelGGL(k_scatter, gb, tb, 0, s, n, w->aabb.p, w->bucket_of.p, w->bucket_cursor.p, w->bucket_start.p,
                        w->sorted_ids.p, w->sorted_box.p); }
+    }
     // small scenes are latency-bound: 4 lanes per body shorten the dependent chain; large scenes are
     // throughput-bound: one lane per body does the least total work
     if (n <= 200000u) {

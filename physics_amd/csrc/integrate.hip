@@ -106,8 +106,12 @@ __global__ __launch_bounds__(256) void k_step_velocity_aabb(StepParams sp, const
                                                             const float* __restrict__ inv_inertia,
                                                             const uint32_t* __restrict__ shape,
                                                             const float* __restrict__ half_extent, float margin,
-                                                            float* __restrict__ aabb, StepCounters* __restrict__ ctr) {
+                                                            float* __restrict__ aabb, StepCounters* __restrict__ ctr,
+                                                            uint4* __restrict__ zero_base, uint32_t zero_count) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    // first kernel of the step: it also zeroes the per-step state of the stages behind it (bucket counts,
+    // colouring state, counters up to max_extent_bits) instead of a memset launch in front of it
+    for (uint32_t z = i; z < zero_count; z += gridDim.x * blockDim.x) zero_base[z] = make_uint4(0u, 0u, 0u, 0u);
     float ext = 0.0f;
     if (i < sp.n) {
         v3 F = v3_make(0.0f, 0.0f, 0.0f), T = v3_make(0.0f, 0.0f, 0.0f);
@@ -267,8 +271,10 @@ void launch_step_full(phys_world* w, float dt, bool gravity) {
     w->forces_dirty = false;
 }
 
-void launch_step_velocity_aabb(phys_world* w, float dt, bool gravity) {
+void launch_step_velocity_aabb(phys_world* w, float dt, bool gravity, bool zero_step) {
     if (w->n == 0) return;
+    uint4* zero_base = zero_step ? reinterpret_cast<uint4*>(w->step_zero.p) : nullptr;
+    const uint32_t zero_count = zero_step ? (uint32_t)(w->step_zero_reset_bytes / 16) : 0u;
     const StepParams sp = make_params(w, dt);
     const dim3 g = grid_for(w->n), b(256);
     const bool diag = w->all_diag_inertia;
@@ -276,7 +282,7 @@ void launch_step_velocity_aabb(phys_world* w, float dt, bool gravity) {
 #define LAUNCH(F, G, D)                                                                                            \
     hipLaunchKernelGGL((k_step_velocity_aabb<F, G, D>), g, b, 0, w->stream, sp, w->pos.p, w->rot.p, w->vel.p,      \
                        w->force.p, w->torque.p, D ? w->inv_inertia_diag.p : w->inv_inertia.p, w->shape.p,                \
-                       w->half_extent.p, margin, w->aabb.p, w->counters.p)
+                       w->half_extent.p, margin, w->aabb.p, w->counters.p, zero_base, zero_count)
     const int sel = (w->forces_dirty ? 4 : 0) | (gravity ? 2 : 0) | (diag ? 1 : 0);
     PHYS_PROF(w, PHYS_STAGE_VELOCITY_AABB);
     switch (sel) {

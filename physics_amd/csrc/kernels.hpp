@@ -50,7 +50,7 @@ __device__ __forceinline__ void st_vel(float* __restrict__ vel, uint32_t i, cons
 
 // integrate.hip
 void launch_step_full(phys_world* w, float dt, bool gravity);
-void launch_step_velocity_aabb(phys_world* w, float dt, bool gravity);
+void launch_step_velocity_aabb(phys_world* w, float dt, bool gravity, bool zero_step);  // zero_step: also zero the per-step state
 void launch_aabb_only(phys_world* w);
 void launch_step_position(phys_world* w, float dt);
 void launch_apply_gravity(phys_world* w);
@@ -67,6 +67,8 @@ int32_t sorted_pairs_to_host(phys_world* w, uint32_t* pairs_out, uint64_t cap, u
 void launch_narrowphase(phys_world* w);
 void launch_coloring(phys_world* w);
 void snapshot_counters_async(phys_world* w);  // abi.hip
+StepCounters* snapshot_acquire(phys_world* w);  // abi.hip: pinned slot a kernel may fill itself ...
+void snapshot_commit(phys_world* w);             // ... then mark it in flight
 void poll_snapshots(phys_world* w);           // abi.hip
 void launch_solver(phys_world* w, float dt);
 

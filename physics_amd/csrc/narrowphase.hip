@@ -163,13 +163,15 @@ constexpr int kColorThreads = 1024;
 // body of one round for the manifolds m = first, first + stride, ...; returns this lane's wins
 template <bool BYPASS_L1>
 __device__ __forceinline__ uint32_t color_round_lanes(uint32_t first, uint32_t stride, uint32_t M,
+                                                      const uint32_t* list /* null: every manifold; else M ids */,
                                                       const uint32_t* __restrict__ man_a, const uint32_t* __restrict__ man_b,
                                                       uint32_t* __restrict__ man_color, const uint64_t* __restrict__ man_prio,
                                                       const unsigned long long* top, unsigned long long* top_next,
                                                       unsigned long long* top_clr, unsigned long long* used,
                                                       StepCounters* __restrict__ ctr) {
     uint32_t wins = 0;
-    for (uint32_t m = first; m < M; m += stride) {
+    for (uint32_t i = first; i < M; i += stride) {
+        const uint32_t m = list ? list[i] : i;
         if (man_color[m] != kUncolored) continue;
         const unsigned long long p = man_prio[m];
         const uint32_t a = man_a[m], b = man_b[m];
@@ -234,7 +236,7 @@ __global__ __launch_bounds__(kColorThreads) void k_color_round(uint32_t round, u
     __syncthreads();
     if (s_uncolored == 0) return;
     const uint32_t M = stored_manifolds(ctr, max_manifolds);
-    uint32_t wins = color_round_lanes<false>(blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x, M, man_a, man_b,
+    uint32_t wins = color_round_lanes<false>(blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x, M, nullptr, man_a, man_b,
                                              man_color, man_prio, top, top_next, top_clr, used, ctr);
     // ONE global atomic per workgroup (same-address atomics serialise chip-wide at ~88 per microsecond)
 #pragma unroll
@@ -274,7 +276,7 @@ __global__ __launch_bounds__(kColorThreads) void k_color_finish(uint32_t round, 
         unsigned long long* top = state + (1 + round % 3) * n;
         unsigned long long* top_next = state + (1 + (round + 1) % 3) * n;
         unsigned long long* top_clr = state + (1 + (round + 2) % 3) * n;
-        uint32_t wins = color_round_lanes<true>(threadIdx.x, kColorThreads, M, man_a, man_b, man_color, man_prio, top,
+        uint32_t wins = color_round_lanes<true>(threadIdx.x, kColorThreads, M, nullptr, man_a, man_b, man_color, man_prio, top,
                                                 top_next, top_clr, used, ctr);
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) wins += (uint32_t)__shfl_xor((int)wins, off, 64);
@@ -422,17 +424,99 @@ __global__ __launch_bounds__(1024) void k_color_place(uint64_t max_manifolds, co
     }
 }
 
-// small manifold counts: histogram, offsets and placement of the colour-major renumbering in ONE workgroup
-// (one launch instead of three)
-__global__ __launch_bounds__(1024) void k_color_sort_small(uint64_t max_manifolds, const uint32_t* __restrict__ man_color,
-                                                           uint32_t* __restrict__ row_src, StepCounters* __restrict__ ctr) {
+// Small scenes (<= 24k manifolds): the WHOLE colouring stage in ONE launch of ONE workgroup - every
+// Jones-Plassmann round (over a list of the uncoloured manifolds gathered into LDS: with persistent colouring
+// only the new ones), the colour-major counting sort, and the snapshot of the counters into pinned host memory
+// (the launch-size hints of later steps) - instead of ~3 round launches + finish + sort + a copy.
+constexpr int kSmallList = 8192;
+constexpr int kSmallTrips = 24;  // manifolds per thread kept in registers: 24 x 1024 = the `small` limit of launch_coloring
+__global__ __launch_bounds__(kColorThreads) void k_color_small(uint64_t max_manifolds, const uint32_t* __restrict__ man_a,
+                                                              const uint32_t* __restrict__ man_b, uint32_t* man_color,
+                                                              const uint64_t* __restrict__ man_prio,
+                                                              unsigned long long* __restrict__ state /*4n*/, uint64_t n,
+                                                              uint32_t* __restrict__ row_src, StepCounters* ctr,
+                                                              StepCounters* snap_out /* host-mapped, may be null */) {
+    __shared__ uint32_t s_list[kSmallList];
+    __shared__ uint32_t s_n, s_left;
+    __shared__ uint32_t s_wins[kColorThreads / 64];
     __shared__ uint32_t h[PHYS_MAX_COLORS], cursor[PHYS_MAX_COLORS];
-    if (threadIdx.x < PHYS_MAX_COLORS) h[threadIdx.x] = 0;
-    __syncthreads();
     const uint32_t M = stored_manifolds(ctr, max_manifolds);
-    for (uint32_t m = threadIdx.x; m < M; m += 1024) {
-        const uint32_t c = man_color[m];
-        if (c < (uint32_t)PHYS_MAX_COLORS) atomicAdd(&h[c], 1u);
+    if (threadIdx.x == 0) { s_n = 0; s_left = ctr->n_uncolored; }
+    if (threadIdx.x < PHYS_MAX_COLORS) h[threadIdx.x] = 0;
+    // the colours of this thread's manifolds (m = k * 1024 + thread) stay in registers for all three passes
+    // (gather the uncoloured, histogram, placement); a larger M than the launch expected takes the slow loops
+    const bool in_regs = M <= (uint32_t)(kSmallTrips * kColorThreads);
+    uint32_t col[kSmallTrips];
+    if (in_regs) {
+#pragma unroll
+        for (int k = 0; k < kSmallTrips; ++k) {
+            const uint32_t m = k * kColorThreads + threadIdx.x;
+            col[k] = m < M ? man_color[m] : 0xFFFFFFFEu;  // neither a colour nor kUncolored
+        }
+    }
+    __syncthreads();
+    uint32_t left = s_left;
+    if (left != 0 && left <= M) {
+        if (in_regs) {
+#pragma unroll
+            for (int k = 0; k < kSmallTrips; ++k) {
+                if (col[k] == kUncolored) {
+                    const uint32_t at = atomicAdd(&s_n, 1u);
+                    if (at < (uint32_t)kSmallList) s_list[at] = k * kColorThreads + threadIdx.x;
+                }
+            }
+        } else {
+            for (uint32_t m = threadIdx.x; m < M; m += kColorThreads) {
+                if (man_color[m] == kUncolored) {
+                    const uint32_t at = atomicAdd(&s_n, 1u);
+                    if (at < (uint32_t)kSmallList) s_list[at] = m;
+                }
+            }
+        }
+        __syncthreads();
+        const bool listed = s_n <= (uint32_t)kSmallList;
+        const uint32_t* list = listed ? s_list : nullptr;
+        const uint32_t count = listed ? s_n : M;
+        unsigned long long* used = state;
+        uint32_t round = 0;
+        while (left != 0) {
+            unsigned long long* top = state + (1 + round % 3) * n;
+            unsigned long long* top_next = state + (1 + (round + 1) % 3) * n;
+            unsigned long long* top_clr = state + (1 + (round + 2) % 3) * n;
+            uint32_t wins = color_round_lanes<true>(threadIdx.x, kColorThreads, count, list, man_a, man_b, man_color, man_prio,
+                                                    top, top_next, top_clr, used, ctr);
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) wins += (uint32_t)__shfl_xor((int)wins, off, 64);
+            if ((threadIdx.x & 63) == 0) s_wins[threadIdx.x >> 6] = wins;
+            __threadfence();  // this round's stores and atomics are performed before anyone starts the next
+            __syncthreads();
+            uint32_t t = 0;
+            for (int k = 0; k < kColorThreads / 64; ++k) t += s_wins[k];
+            left -= t;
+            ++round;
+            __syncthreads();
+            if (t == 0) break;  // cannot happen (the highest priority always wins); never spin
+        }
+        if (threadIdx.x == 0) {
+            ctr->n_uncolored = left;
+            ctr->color_rounds = round;
+        }
+        if (in_regs) {  // colours other waves of this workgroup wrote: read past the L1
+#pragma unroll
+            for (int k = 0; k < kSmallTrips; ++k)
+                if (col[k] == kUncolored)
+                    col[k] = __hip_atomic_load(&man_color[k * kColorThreads + threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    // colour-major counting sort
+    if (in_regs) {
+#pragma unroll
+        for (int k = 0; k < kSmallTrips; ++k) if (col[k] < (uint32_t)PHYS_MAX_COLORS) atomicAdd(&h[col[k]], 1u);
+    } else {
+        for (uint32_t m = threadIdx.x; m < M; m += kColorThreads) {
+            const uint32_t c = __hip_atomic_load(&man_color[m], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (c < (uint32_t)PHYS_MAX_COLORS) atomicAdd(&h[c], 1u);
+        }
     }
     __syncthreads();
     if (threadIdx.x < PHYS_MAX_COLORS) {  // one wave: exclusive scan of the 64 counts
@@ -456,10 +540,23 @@ __global__ __launch_bounds__(1024) void k_color_sort_small(uint64_t max_manifold
         }
         if (threadIdx.x == 0) ctr->n_colors = cmax;
     }
+    __threadfence();
     __syncthreads();
-    for (uint32_t m = threadIdx.x; m < M; m += 1024) {
-        const uint32_t c = man_color[m];
-        if (c < (uint32_t)PHYS_MAX_COLORS) row_src[atomicAdd(&cursor[c], 1u)] = m;
+    if (in_regs) {
+#pragma unroll
+        for (int k = 0; k < kSmallTrips; ++k)
+            if (col[k] < (uint32_t)PHYS_MAX_COLORS) row_src[atomicAdd(&cursor[col[k]], 1u)] = k * kColorThreads + threadIdx.x;
+    } else {
+        for (uint32_t m = threadIdx.x; m < M; m += kColorThreads) {
+            const uint32_t c = __hip_atomic_load(&man_color[m], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (c < (uint32_t)PHYS_MAX_COLORS) row_src[atomicAdd(&cursor[c], 1u)] = m;
+        }
+    }
+    if (snap_out) {  // the counters as they stand after the colouring stage
+        const uint32_t words = (uint32_t)(sizeof(StepCounters) / 4);
+        if (threadIdx.x < words)
+            reinterpret_cast<uint32_t*>(snap_out)[threadIdx.x] =
+                __hip_atomic_load(reinterpret_cast<uint32_t*>(ctr) + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -518,6 +615,18 @@ void launch_coloring(phys_world* w) {
     const bool full = ((w->color_epoch % PHYS_COLOR_CACHE_PERIOD) == 0) || !w->ctab_valid;
     w->snap_tag_full = full;
     const bool known = w->hint.valid && (!full || w->hint.full_rounds > 0);
+    const bool small = w->hint.valid && w->hint.n_manifolds <= 24576u;
+    bool snapshot_done = false;
+    if (small) {
+        // one workgroup does the whole stage, snapshot of the counters included
+        StepCounters* slot = snapshot_acquire(w);
+        StepCounters* d_slot = nullptr;
+        if (slot && hipHostGetDevicePointer((void**)&d_slot, slot, 0) != hipSuccess) d_slot = nullptr;
+        { PHYS_PROF(w, PHYS_STAGE_COLOR);
+          hipLaunchKernelGGL(k_color_small, dim3(1), dim3(kColorThreads), 0, s, w->max_manifolds, w->man_a.p, w->man_b.p,
+                             w->man_color.p, w->man_prio.p, w->color_state.p, (uint64_t)n, w->row_src.p, w->counters.p, d_slot); }
+        if (d_slot) { snapshot_commit(w); snapshot_done = true; }
+    } else {
     if (known) {
         const uint32_t base = full ? w->hint.full_rounds : w->hint.color_rounds;
         rounds = base + 2 + base / 4;  // surplus launches exit at once; k_color_finish covers a miss
@@ -541,13 +650,9 @@ void launch_coloring(phys_world* w) {
         nb = 1;
         while (nb < want && nb < (uint32_t)kSortBlocksMax) nb <<= 1;
     }
-    if (w->hint.valid && w->hint.n_manifolds <= 24576u) {
-        PHYS_PROF(w, PHYS_STAGE_ROWS);
-        hipLaunchKernelGGL(k_color_sort_small, dim3(1), dim3(1024), 0, s, w->max_manifolds, w->man_color.p, w->row_src.p, w->counters.p);
-    } else {
-        { PHYS_PROF(w, PHYS_STAGE_ROWS); hipLaunchKernelGGL(k_color_hist, dim3(nb), dim3(1024), 0, s, w->max_manifolds, w->man_color.p, w->color_block_hist.p, nb, w->counters.p); }
-        { PHYS_PROF(w, PHYS_STAGE_ROWS); hipLaunchKernelGGL(k_color_offsets, dim3(1), dim3(1024), 0, s, w->color_block_hist.p, nb, w->counters.p); }
-        { PHYS_PROF(w, PHYS_STAGE_ROWS); hipLaunchKernelGGL(k_color_place, dim3(nb), dim3(1024), 0, s, w->max_manifolds, w->man_color.p, w->color_block_hist.p, nb, w->row_src.p, w->counters.p); }
+    { PHYS_PROF(w, PHYS_STAGE_ROWS); hipLaunchKernelGGL(k_color_hist, dim3(nb), dim3(1024), 0, s, w->max_manifolds, w->man_color.p, w->color_block_hist.p, nb, w->counters.p); }
+    { PHYS_PROF(w, PHYS_STAGE_ROWS); hipLaunchKernelGGL(k_color_offsets, dim3(1), dim3(1024), 0, s, w->color_block_hist.p, nb, w->counters.p); }
+    { PHYS_PROF(w, PHYS_STAGE_ROWS); hipLaunchKernelGGL(k_color_place, dim3(nb), dim3(1024), 0, s, w->max_manifolds, w->man_color.p, w->color_block_hist.p, nb, w->row_src.p, w->counters.p); }
     }
     {
         // colour table of this update for the next one (the slot it overwrites was read two updates ago)
@@ -569,7 +674,7 @@ void launch_coloring(phys_world* w) {
         w->ctab_valid = true;
         w->color_epoch++;
     }
-    if (!known) {
+    if (!known && !small) {
         // ... and adopts the exact counters as the first hint (the solver launches right after use them)
         (void)hipMemcpyAsync(w->h_counters, w->counters.p, sizeof(StepCounters), hipMemcpyDeviceToHost, s);
         (void)hipStreamSynchronize(s);
@@ -581,7 +686,7 @@ void launch_coloring(phys_world* w) {
             if (full) w->hint.full_rounds = c.color_rounds; else w->hint.color_rounds = c.color_rounds;
             for (int q = 0; q < kMaxColors; ++q) w->hint.color_count[q] = c.color_count[q];
         }
-    } else {
+    } else if (!snapshot_done) {
         snapshot_counters_async(w);
     }
 }
