@@ -11,6 +11,13 @@
  *       every manifold of that colour, in any order (they share no body)
  *   inside a manifold: points in index order; per point tangent 1, tangent 2, then normal.
  *
+ * A row (point k, direction d) is solved in Jacobian form: with aA = rA x d, aB = rB x d (angular Jacobians),
+ * mA = IA aA, mB = IB aB and lA = d invMA, lB = d invMB - all independent of the velocities, computed once per
+ * solve of a manifold (solver_jacobians) - the relative velocity along d is (d.vB + aB.wB) - (d.vA + aA.wA) and
+ * an impulse lambda changes the velocities by -lA lambda, -mA lambda, +lB lambda, +mB lambda. The sequential
+ * part of a row is therefore four dot products, a clamp and four axpys (the latency of a parallel solve is
+ * the length of exactly this chain, times the rows of a manifold, times colours, times iterations).
+ *
  * Colouring (Jones-Plassmann on the line graph, synchronous rounds; a pure function of the SET of
  * manifolds, independent of their storage order):
  *   priority(m) = mix64(a << 32 | b)           (bijective, so priorities are distinct)
@@ -113,49 +120,127 @@ PHYS_HD void solver_prep(const manifold_t* m, int has_b, v3 xA, v3 xB, float inv
     }
 }
 
-PHYS_HD void apply_impulse(v3 P, v3 rA, v3 rB, float invMA, const m33* IA, float invMB, const m33* IB, int has_b,
-                           v3* vA, v3* wA, v3* vB, v3* wB) {
-    *vA = v3_sub(*vA, v3_scale(P, invMA));
-    *wA = v3_sub(*wA, m33_mul_v3(IA, v3_cross(rA, P)));
-    if (has_b) {
-        *vB = v3_add(*vB, v3_scale(P, invMB));
-        *wB = v3_add(*wB, m33_mul_v3(IB, v3_cross(rB, P)));
+/* velocity-independent part of the rows of one manifold; d = 0: t1, 1: t2, 2: n */
+typedef struct {
+    v3 aA, aB; /* r x dir */
+    v3 mA, mB; /* I^-1 (r x dir) */
+} jac_row_t;
+
+typedef struct {
+    v3 lA[3], lB[3]; /* dir * inverse mass */
+    jac_row_t j[4][3];
+} solver_jac_t;
+
+PHYS_HD void jac_row_make(const solver_manifold_t* sm, int k, v3 dir, const m33* IA, const m33* IB, jac_row_t* j) {
+    const v3 zero = v3_make(0.0f, 0.0f, 0.0f);
+    j->aA = v3_cross(sm->row[k].rA, dir);
+    j->mA = m33_mul_v3(IA, j->aA);
+    if (sm->has_b) {
+        j->aB = v3_cross(sm->row[k].rB, dir);
+        j->mB = m33_mul_v3(IB, j->aB);
+    } else {
+        j->aB = zero; j->mB = zero;
     }
 }
 
-PHYS_HD v3 relative_velocity(v3 rA, v3 rB, int has_b, v3 vA, v3 wA, v3 vB, v3 wB) {
-    const v3 pa = v3_add(vA, v3_cross(wA, rA));
-    if (!has_b) return v3_neg(pa);
-    const v3 pb = v3_add(vB, v3_cross(wB, rB));
-    return v3_sub(pb, pa);
+PHYS_HD void solver_jacobians(const solver_manifold_t* sm, float invMA, const m33* IA, float invMB, const m33* IB,
+                              solver_jac_t* J) {
+    const v3 zero = v3_make(0.0f, 0.0f, 0.0f);
+    PHYS_UNROLL
+    for (int d = 0; d < 3; ++d) {
+        const v3 dir = d == 0 ? sm->t1 : (d == 1 ? sm->t2 : sm->n);
+        J->lA[d] = v3_scale(dir, invMA);
+        J->lB[d] = sm->has_b ? v3_scale(dir, invMB) : zero;
+    }
+    PHYS_UNROLL
+    for (int k = 0; k < 4; ++k) {
+        PHYS_UNROLL
+        for (int d = 0; d < 3; ++d) {
+            jac_row_t* j = &J->j[k][d];
+            if (k < sm->count) {
+                jac_row_make(sm, k, d == 0 ? sm->t1 : (d == 1 ? sm->t2 : sm->n), IA, IB, j);
+            } else {
+                j->aA = zero; j->aB = zero; j->mA = zero; j->mB = zero;
+            }
+        }
+    }
 }
 
-/* one Gauss-Seidel sweep over the points of one manifold; velocities are updated in place */
-PHYS_HD void solve_manifold(solver_manifold_t* sm, float friction, float invMA, const m33* IA, float invMB,
-                            const m33* IB, v3* vA, v3* wA, v3* vB, v3* wB) {
+/* relative velocity of the contact point along dir (body B minus body A) */
+PHYS_HD float row_velocity(v3 dir, const jac_row_t* j, int has_b, v3 vA, v3 wA, v3 vB, v3 wB) {
+    const float ua = v3_dot(dir, vA) + v3_dot(j->aA, wA);
+    if (!has_b) return -ua;
+    const float ub = v3_dot(dir, vB) + v3_dot(j->aB, wB);
+    return ub - ua;
+}
+
+PHYS_HD void row_apply(float lambda, v3 lA, v3 lB, const jac_row_t* j, int has_b, v3* vA, v3* wA, v3* vB, v3* wB) {
+    *vA = v3_sub(*vA, v3_scale(lA, lambda));
+    *wA = v3_sub(*wA, v3_scale(j->mA, lambda));
+    if (has_b) {
+        *vB = v3_add(*vB, v3_scale(lB, lambda));
+        *wB = v3_add(*wB, v3_scale(j->mB, lambda));
+    }
+}
+
+/* one row: friction direction t (0, 1) or the normal (t = 2) of point k */
+PHYS_HD void solve_row_dir(solver_manifold_t* sm, int k, int t, const jac_row_t* j, v3 lA, v3 lB, float friction, v3* vA,
+                           v3* wA, v3* vB, v3* wB) {
+    contact_row_t* r = &sm->row[k];
     const int has_b = sm->has_b;
+    if (t < 2) {
+        const v3 dir = t == 0 ? sm->t1 : sm->t2;
+        const float vt = row_velocity(dir, j, has_b, *vA, *wA, *vB, *wB);
+        float lambda = -r->tangent_mass[t] * vt;
+        const float maxf = friction * r->pn;
+        const float old = r->pt[t];
+        const float np = det_maxf(-maxf, det_minf(old + lambda, maxf));
+        lambda = np - old;
+        r->pt[t] = np;
+        row_apply(lambda, lA, lB, j, has_b, vA, wA, vB, wB);
+    } else {
+        const float vn = row_velocity(sm->n, j, has_b, *vA, *wA, *vB, *wB);
+        float lambda = r->normal_mass * (r->bias - vn);
+        const float old = r->pn;
+        const float np = det_maxf(old + lambda, 0.0f);
+        lambda = np - old;
+        r->pn = np;
+        row_apply(lambda, lA, lB, j, has_b, vA, wA, vB, wB);
+    }
+}
+
+/* one Gauss-Seidel sweep over the points of one manifold; velocities are updated in place. Two drivers of the
+ * SAME arithmetic: with the Jacobians made beforehand (the sequential part is then as short as it gets) ... */
+PHYS_HD void solve_manifold(solver_manifold_t* sm, const solver_jac_t* J, float friction, v3* vA, v3* wA, v3* vB, v3* wB) {
+    PHYS_UNROLL
     for (int k = 0; k < 4; ++k) {
-        if (k >= sm->count) break;
-        contact_row_t* r = &sm->row[k];
-        for (int t = 0; t < 2; ++t) {
-            const v3 dir = t == 0 ? sm->t1 : sm->t2;
-            const v3 dv = relative_velocity(r->rA, r->rB, has_b, *vA, *wA, *vB, *wB);
-            float lambda = -r->tangent_mass[t] * v3_dot(dv, dir);
-            const float maxf = friction * r->pn;
-            const float old = r->pt[t];
-            const float np = det_maxf(-maxf, det_minf(old + lambda, maxf));
-            lambda = np - old;
-            r->pt[t] = np;
-            apply_impulse(v3_scale(dir, lambda), r->rA, r->rB, invMA, IA, invMB, IB, has_b, vA, wA, vB, wB);
+        if (k < sm->count) {
+            PHYS_UNROLL
+            for (int t = 0; t < 3; ++t) solve_row_dir(sm, k, t, &J->j[k][t], J->lA[t], J->lB[t], friction, vA, wA, vB, wB);
         }
-        {
-            const v3 dv = relative_velocity(r->rA, r->rB, has_b, *vA, *wA, *vB, *wB);
-            float lambda = r->normal_mass * (r->bias - v3_dot(dv, sm->n));
-            const float old = r->pn;
-            const float np = det_maxf(old + lambda, 0.0f);
-            lambda = np - old;
-            r->pn = np;
-            apply_impulse(v3_scale(sm->n, lambda), r->rA, r->rB, invMA, IA, invMB, IB, has_b, vA, wA, vB, wB);
+    }
+}
+
+/* ... or made row by row on the way (one quarter of the registers; same values, same results) */
+PHYS_HD void solve_manifold_lazy(solver_manifold_t* sm, float friction, float invMA, const m33* IA, float invMB,
+                                 const m33* IB, v3* vA, v3* wA, v3* vB, v3* wB) {
+    const v3 zero = v3_make(0.0f, 0.0f, 0.0f);
+    v3 lA[3], lB[3];
+    PHYS_UNROLL
+    for (int d = 0; d < 3; ++d) {
+        const v3 dir = d == 0 ? sm->t1 : (d == 1 ? sm->t2 : sm->n);
+        lA[d] = v3_scale(dir, invMA);
+        lB[d] = sm->has_b ? v3_scale(dir, invMB) : zero;
+    }
+    PHYS_UNROLL
+    for (int k = 0; k < 4; ++k) {
+        if (k < sm->count) {
+            PHYS_UNROLL
+            for (int t = 0; t < 3; ++t) {
+                jac_row_t j;
+                jac_row_make(sm, k, t == 0 ? sm->t1 : (t == 1 ? sm->t2 : sm->n), IA, IB, &j);
+                solve_row_dir(sm, k, t, &j, lA[t], lB[t], friction, vA, wA, vB, wB);
+            }
         }
     }
 }

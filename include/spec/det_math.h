@@ -19,8 +19,10 @@
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define PHYS_HD __host__ __device__ __forceinline__
+#define PHYS_UNROLL _Pragma("unroll")
 #else
 #define PHYS_HD static inline
+#define PHYS_UNROLL
 #endif
 
 /* plain comparisons: no fminf/fmaxf (their NaN / signed-zero rules differ between libms) */

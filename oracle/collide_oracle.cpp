@@ -241,8 +241,8 @@ void CollisionWorld::solve(std::vector<RigidBody>& bodies, float dt) {
                 v3 vA = V(A.lin_velocity), wA = V(A.angular_velocity);
                 v3 vB = v3_make(0, 0, 0), wB = v3_make(0, 0, 0);
                 if (has_b) { vB = V(bodies[mf.b].lin_velocity); wB = V(bodies[mf.b].angular_velocity); }
-                solve_manifold(&rows[m], sp.friction, inv_mass[mf.a], &inv_inertia[mf.a], has_b ? inv_mass[mf.b] : 0.0f,
-                               has_b ? &inv_inertia[mf.b] : &zero, &vA, &wA, &vB, &wB);
+                solve_manifold_lazy(&rows[m], sp.friction, inv_mass[mf.a], &inv_inertia[mf.a], has_b ? inv_mass[mf.b] : 0.0f,
+                                    has_b ? &inv_inertia[mf.b] : &zero, &vA, &wA, &vB, &wB);
                 A.lin_velocity[0] = vA.x; A.lin_velocity[1] = vA.y; A.lin_velocity[2] = vA.z;
                 A.angular_velocity[0] = wA.x; A.angular_velocity[1] = wA.y; A.angular_velocity[2] = wA.z;
                 if (has_b) {

@@ -190,7 +190,9 @@ __device__ __forceinline__ void solve_row(uint32_t d, const RowArrays& rows, flo
     v3 vB = v3_make(0.0f, 0.0f, 0.0f), wB = v3_make(0.0f, 0.0f, 0.0f);
     BodyVel B = A;
     if (sm.has_b) { IB = ld_inertia<DIAG>(inv_inertia, b * inertia_stride); B = ld_vel(vel, b); imb = B.inv_mass; vB = B.v; wB = B.w; }
-    solve_manifold(&sm, friction, ima, &IA, imb, &IB, &vA, &wA, &vB, &wB);
+    // rows made on the way: these kernels are throughput-bound and want the registers (k_solve_flow makes them all
+    // beforehand, while it waits; same arithmetic)
+    solve_manifold_lazy(&sm, friction, ima, &IA, imb, &IB, &vA, &wA, &vB, &wB);
     A.v = vA; A.w = wA;
     st_vel(vel, a, A);
     if (sm.has_b) { B.v = vB; B.w = wB; st_vel(vel, b, B); }
@@ -331,6 +333,9 @@ __global__ __launch_bounds__(256) void k_solve_flow(StepCounters* __restrict__ c
                 imb = B0.inv_mass; massB = B0.mass; vB = B0.v; wB = B0.w;
             }
         }
+        // the velocity-independent part of every row, while the row waits: the chain behind the wait is short
+        solver_jac_t J;
+        solver_jacobians(&R.sm, ima, &IA, imb, &IB, &J);
         // what is still missing (a matched granule cannot change any more: this row is its next writer)
         bool needA = !done && tA != 0, needB = !done && R.sm.has_b && tB != 0, needAcc = !done && it != 0;
         uint32_t sweeps = 0;
@@ -378,7 +383,7 @@ __global__ __launch_bounds__(256) void k_solve_flow(StepCounters* __restrict__ c
                     }
                 }
                 if (!needA && !needB && !needAcc) {
-                    solve_manifold(&R.sm, friction, ima, &IA, imb, &IB, &vA, &wA, &vB, &wB);
+                    solve_manifold(&R.sm, &J, friction, &vA, &wA, &vB, &wB);
                     // publish: bodies first (they are what other rows wait for)
                     if (finalA) { BodyVel o; o.v = vA; o.inv_mass = ima; o.w = wA; o.mass = massA; st_vel(vel, R.a, o); }
                     else { st_granule(rv, R.a * 32u, vA, etag | (tA + 1u)); st_granule(rv, R.a * 32u + 16u, wA, etag | (tA + 1u)); }
