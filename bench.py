@@ -64,16 +64,18 @@ def stage_bytes(stage, st, iters):
 
 
 def rocprof_avg_us(workload_key, kernel):
-    """Average kernel duration from the committed rocprofv3 --kernel-trace --stats summary of this same script
-    (profiles/r1_<workload>_kernel_stats.csv). HIP-event brackets (avg_launch_us) additionally contain the
-    dispatch of the launch (about 2-4 us), so they read higher than rocprof's begin-to-end kernel time."""
+    """Average kernel duration from the committed rocprofv3 --kernel-trace run of this same script: the per-kernel
+    statistics of the launches of its profile pass (profiles/r1_<workload>_profile_pass_stats.csv, cut out of the
+    trace by tools/trace_tail.py; the whole-run --stats summary is r1_<workload>_kernel_stats.csv). HIP-event
+    brackets (avg_launch_us) additionally contain the dispatch of the launch (about 2-4 us per launch)."""
     import csv
-    path = os.path.join(ROOT, "profiles", f"r1_{workload_key}_kernel_stats.csv")
-    if not os.path.exists(path):
-        return None
-    for row in csv.DictReader(open(path)):
-        if row["Name"].split("(")[0].split("<")[0].endswith(kernel):
-            return round(float(row["AverageNs"]) / 1e3, 3)
+    for name in (f"r1_{workload_key}_profile_pass_stats.csv", f"r1_{workload_key}_kernel_stats.csv"):
+        path = os.path.join(ROOT, "profiles", name)
+        if not os.path.exists(path):
+            continue
+        for row in csv.DictReader(open(path)):
+            if row["Name"].split("(")[0].split("<")[0].endswith(kernel):
+                return round(float(row["AverageNs"]) / 1e3, 3)
     return None
 
 
