@@ -164,6 +164,26 @@ def profile_pass(world, steps, iters, workload_key="c2"):
     return roof, table, st
 
 
+def copy_ceiling_gbs(device):
+    """Second denominator: what a plain device-to-device copy reaches on this box, read + write
+    bytes per second, best of 5 copies of 1 GiB."""
+    import torch
+    n = 1 << 30
+    a = torch.empty(n, dtype=torch.uint8, device=device)
+    b = torch.empty(n, dtype=torch.uint8, device=device)
+    b.copy_(a)
+    best = 0.0
+    for _ in range(5):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        b.copy_(a)
+        e1.record()
+        e1.synchronize()
+        best = max(best, 2.0 * n / (e0.elapsed_time(e1) * 1e-3) / 1e9)
+    del a, b
+    return round(best, 1)
+
+
 def cpu_baseline(scene, preroll, sample_steps):
     from oracle import binding as ob
     from physics_amd.scenes import DT_NANOS
@@ -281,6 +301,9 @@ def main():
             "scene_stats": st,
         }
         if roof is not None:
+            if not sharded:
+                roof["copy_ceiling"] = copy_ceiling_gbs(f"cuda:{local_rank}")  # GB/s a device-to-device copy reaches here
+                roof["frac_of_copy_ceiling"] = round(roof["achieved"] / roof["copy_ceiling"], 5)
             out["roofline"] = roof
             out["stages"] = {k: {kk: round(vv, 3) for kk, vv in v.items()} for k, v in table.items()}
     elif halo is None:

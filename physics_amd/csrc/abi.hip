@@ -54,7 +54,10 @@ void poll_snapshots(phys_world* w) {
     for (int i = 0; i < phys_world::kSnapRing; ++i) {
         const uint32_t k = (w->snap_next + i) % phys_world::kSnapRing;
         if (!w->snap_pending[k]) continue;
-        if (hipEventQuery(w->snap_event[k]) != hipSuccess) continue;
+        if (hipEventQuery(w->snap_event[k]) != hipSuccess) {
+            (void)hipGetLastError();  // hipErrorNotReady is an answer, not a failure: do not leave it behind as the
+            continue;                 // thread's sticky error for whoever calls HIP next (the host application)
+        }
         const StepCounters& c = *w->h_snap[k];
         w->snap_pending[k] = false;
         if (c.overflow) continue;

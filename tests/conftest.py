@@ -27,6 +27,18 @@ def _gpu_available():
         return False
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _torch_gpu_first():
+    """On a GPU box, bring PyTorch's HIP context up before libphysics_hip touches the device: tests that open
+    torch streams / RCCL groups later then never depend on which other tests ran before them (initialising torch
+    after the library had been used failed with hipErrorNoDevice for one particular subset of tests)."""
+    if _gpu_available():
+        import torch
+        torch.cuda.init()
+        torch.zeros(1, device="cuda")
+    yield
+
+
 @pytest.fixture(scope="session")
 def hip_world_factory():
     """Factory of physics_amd.World on cuda:0. The HIP library must be present: no fallback."""

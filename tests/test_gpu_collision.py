@@ -211,3 +211,42 @@ def test_full_inertia_tensors_and_unequal_masses_bit_exact():
             w.sync()
             _compare_state(w, o, f"full inertia, flags +{extra}, step {50 * (k + 1)}")
         assert w.get_stats().n_contacts > 50
+
+
+def test_dataflow_solver_under_concurrent_load():
+    """The inter-workgroup hand-off of k_solve_flow (data-tagged 16-byte granules, sc1 stores / loads) must not
+    depend on timing: step a contact-rich scene while another stream keeps the memory system and the CUs busy
+    with unrelated copies and GEMMs (uneven load is where a missing fence or a stale L1 line shows up), and
+    compare every bit with the per-colour path run on a quiet GPU."""
+    import torch
+    import physics_amd
+    from physics_amd import scenes
+    sc = scenes.c2()
+    quiet = physics_amd.World(sc.config(flags=sc.flags | physics_amd.FLAG_SOLVER_PER_COLOR))
+    sc.populate(quiet)
+    quiet.update_n(DT, 260)
+    quiet.sync()
+    ref = quiet.get_transforms() + quiet.get_velocities()
+    quiet.close()
+
+    busy = physics_amd.World(sc.config())
+    sc.populate(busy)
+    side = torch.cuda.Stream()
+    a = torch.empty(1 << 28, dtype=torch.uint8, device="cuda")
+    b = torch.empty_like(a)
+    m = torch.randn(4096, 4096, device="cuda", dtype=torch.bfloat16)
+    for k in range(26):
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                b.copy_(a, non_blocking=True)
+                m2 = m @ m
+        busy.update_n(DT, 10)
+        if k % 5 == 0:
+            busy.sync()
+    busy.sync()
+    torch.cuda.synchronize()
+    del m2
+    prof_on = busy.get_stats()
+    assert prof_on.overflow == 0
+    for x, y in zip(busy.get_transforms() + busy.get_velocities(), ref):
+        assert np.array_equal(x, y)
