@@ -250,3 +250,27 @@ def test_dataflow_solver_under_concurrent_load():
     assert prof_on.overflow == 0
     for x, y in zip(busy.get_transforms() + busy.get_velocities(), ref):
         assert np.array_equal(x, y)
+
+
+def test_small_scene_kernels_outgrown_between_two_hints():
+    """The one-workgroup kernels of small scenes (k_color_small) are chosen from a LAGGED manifold count. A layer
+    of 75 x 75 touching cubes (22 052 neighbour manifolds, edge-touching diagonals included: just "small") lands on
+    the plane in one step (+5 625 ground manifolds): for a few steps the kernels meet more manifolds than they were sized for and must still
+    produce the exact colouring, order and solve."""
+    from physics_amd import scenes
+    nx = 75
+    pos = scenes.lattice(nx, 1, nx, 2.0, 1.2, 0.0)
+    st, he = scenes._cubes(pos.shape[0])
+    sc = scenes.Scene("one_layer", pos, st, he, scenes.FLAG_COLLISIONS | scenes.FLAG_GROUND_PLANE)
+    w, o = _worlds(sc.config)
+    for x in (w, o):
+        sc.populate(x)
+    seen = []
+    for k in range(8):
+        w.update_n(DT, 3)
+        o.update_n(DT, 3)
+        w.sync()
+        seen.append(w.get_stats().n_manifolds)
+        _compare_state(w, o, f"one layer, step {3 * (k + 1)}")
+        _compare_manifolds(w, o)
+    assert min(seen) <= 24576 < max(seen), seen
