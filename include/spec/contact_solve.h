@@ -169,8 +169,7 @@ PHYS_HD void solver_jacobians(const solver_manifold_t* sm, float invMA, const m3
 /* relative velocity of the contact point along dir (body B minus body A) */
 PHYS_HD float row_velocity(v3 dir, const jac_row_t* j, int has_b, v3 vA, v3 wA, v3 vB, v3 wB) {
     const float ua = v3_dot(dir, vA) + v3_dot(j->aA, wA);
-    if (!has_b) return -ua;
-    const float ub = v3_dot(dir, vB) + v3_dot(j->aB, wB);
+    const float ub = has_b ? v3_dot(dir, vB) + v3_dot(j->aB, wB) : 0.0f; /* the ground does not move */
     return ub - ua;
 }
 

@@ -278,6 +278,7 @@ __device__ __forceinline__ v3 granule_v3(u32x4 g) {
 
 constexpr long long kFlowTimeoutTicks = 300000000ll;  // 3 s of the 100 MHz wall clock
 constexpr uint64_t kFlowMaxManifolds = 400000;        // above: one launch per colour streams better
+constexpr uint64_t kFlowQuadMaxManifolds = 24000;    // below: four lanes per manifold (k_solve_flow_quad)
 
 template <bool DIAG>
 __global__ __launch_bounds__(256) void k_solve_flow(StepCounters* __restrict__ ctr, uint32_t iterations, uint32_t epoch,
@@ -417,6 +418,216 @@ __global__ __launch_bounds__(256) void k_solve_flow(StepCounters* __restrict__ c
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// The same dataflow solver with FOUR LANES PER MANIFOLD, for scenes where the hop latency is everything. At one
+// wave per SIMD the row solve is VALU-issue-bound (~65 instructions per row x 12 rows, ~2/3 of a hop). A row is
+// four dot products, a scalar update and four axpys over {vA, wA, vB, wB}: lane q of a quad owns ONE of those
+// vectors with its Jacobian column and response (made beforehand, while waiting), so a row costs each lane one
+// dot product, two cross-lane adds (DPP inside the quad: no LDS), the scalar update and one axpy - about a third
+// of the instructions. The partial sums are combined in the order of the spec ((dir.vB + aB.wB) - (dir.vA +
+// aA.wA)), so the bits are those of the one-lane kernels. The granule protocol maps one to one: lane q polls and
+// publishes exactly its own 16-byte granule (v or w of A or B), and the impulse granule of contact point q.
+template <int CTRL>
+__device__ __forceinline__ float quad_perm(float v) {
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+template <int CTRL>
+__device__ __forceinline__ int quad_perm_i(int v) { return __builtin_amdgcn_mov_dpp(v, CTRL, 0xF, 0xF, true); }
+constexpr int kQuadXor1 = 0xB1;  // quad_perm [1, 0, 3, 2]
+constexpr int kQuadXor2 = 0x4E;  // quad_perm [2, 3, 0, 1]
+
+template <bool DIAG>
+__global__ __launch_bounds__(256) void k_solve_flow_quad(StepCounters* __restrict__ ctr, uint32_t iterations, uint32_t epoch,
+                                                         RowArrays rows, float friction,
+                                                         const float* __restrict__ inv_inertia, uint32_t inertia_stride,
+                                                         float* vel, float* flow_vel, uint32_t n_bodies) {
+    __shared__ uint32_t s_item;
+    if (ctr->overflow) return;
+    const uint32_t M = ctr->n_manifolds;
+    const uint32_t rows_per_item = blockDim.x >> 2;
+    const uint32_t nchunks = (M + rows_per_item - 1) / rows_per_item;
+    const uint32_t total = nchunks * iterations;
+    const uint32_t cap = (uint32_t)rows.cap;
+    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(flow_vel, 0, n_bodies * 32u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(rows.acc, 0, cap * 64u, 0x00020000);
+    const uint32_t etag = epoch << 16;
+    const uint32_t q = threadIdx.x & 3u;      // 0: vA, 1: wA, 2: vB, 3: wB
+    const bool side_a = q < 2u, angular = (q & 1u) != 0u;
+    const long long t_start = wall_clock64();
+    const v3 zero = v3_make(0.0f, 0.0f, 0.0f);
+    for (;;) {
+        __syncthreads();
+        if (threadIdx.x == 0)
+            s_item = (__hip_atomic_load(&ctr->overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 16u)
+                         ? 0xFFFFFFFFu : atomicAdd(&ctr->flow_ticket, 1u);
+        __syncthreads();
+        const uint32_t L = s_item;
+        if (L >= total) return;
+        const uint32_t it = L / nchunks, chunk = L - it * nchunks;
+        const bool last_it = it + 1 == iterations;
+        const uint32_t d = chunk * rows_per_item + (threadIdx.x >> 2);
+        bool done = d >= M;  // the same for the four lanes of a quad
+        // per lane: its vector, its Jacobian column and (signed) response for the 12 rows; replicated: the scalars
+        v3 x = zero, Jv[4][3], Rs[4][3];
+        float nm[4], tm0[4], tm1[4], bias[4], pn[4], pt0[4], pt1[4];
+        float keep_w = 0.0f;
+        uint32_t body = 0, count = 0, ticket = 0;
+        bool has_body = false, final_update = false;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            nm[k] = 0.0f; tm0[k] = 0.0f; tm1[k] = 0.0f; bias[k] = 0.0f; pn[k] = 0.0f; pt0[k] = 0.0f; pt1[k] = 0.0f;
+#pragma unroll
+            for (int t = 0; t < 3; ++t) { Jv[k][t] = zero; Rs[k][t] = zero; }
+        }
+        if (!done) {
+            const uint4 h = rows.hdr[d];
+            count = h.z;
+            const bool has_b = h.y != PHYS_GROUND_ID;
+            body = side_a ? h.x : h.y;
+            has_body = side_a || has_b;
+            const uint32_t tk = side_a ? h.w : (h.w >> 16);
+            const uint32_t rank = tk & 0xFFu, deg = (tk >> 8) & 0xFFu;
+            ticket = it * deg + rank;
+            final_update = last_it && rank + 1 == deg;
+            const float4 nn = rows.n[d];
+            v3 dir[3];
+            dir[2] = v3_make(nn.x, nn.y, nn.z);
+            tangent_basis(dir[2], &dir[0], &dir[1]);
+            const float4 t01 = rows.tb[d];
+            float4 t23 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (count > 2) t23 = rows.tb[cap + d];
+            m33 I;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) I.m[k] = 0.0f;
+            float inv_m = 0.0f;
+            if (has_body) {
+                // the body's half of the plain velocity record: the state itself for ticket 0, the masses always
+                const float4 h0 = reinterpret_cast<const float4*>(vel)[2 * (size_t)body + (angular ? 1 : 0)];
+                x = v3_make(h0.x, h0.y, h0.z);
+                keep_w = h0.w;
+                if (angular) I = ld_inertia<DIAG>(inv_inertia, body * inertia_stride); else inv_m = h0.w;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (k < (int)count) {
+                    const float4 p0 = rows.pt[(size_t)(2 * k) * cap + d];      // rA, normal mass
+                    const float4 p1 = rows.pt[(size_t)(2 * k + 1) * cap + d];  // rB, tangent mass 0
+                    nm[k] = p0.w; tm0[k] = p1.w;
+                    const float4 tt = k < 2 ? t01 : t23;
+                    tm1[k] = (k & 1) ? tt.z : tt.x;
+                    bias[k] = (k & 1) ? tt.w : tt.y;
+                    const v3 r = side_a ? v3_make(p0.x, p0.y, p0.z) : v3_make(p1.x, p1.y, p1.z);
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) {
+                        if (has_body) {
+                            // solver_jacobians: lA = dir * invM; aA = r x dir, mA = I aA. The A side is subtracted
+                            // by the spec: its response is stored negated (exact)
+                            v3 jv, rs;
+                            if (angular) { jv = v3_cross(r, dir[t]); rs = m33_mul_v3(&I, jv); }
+                            else { jv = dir[t]; rs = v3_scale(dir[t], inv_m); }
+                            Jv[k][t] = jv;
+                            Rs[k][t] = side_a ? v3_neg(rs) : rs;
+                        }
+                    }
+                }
+            }
+            if (!has_body) x = zero;
+        }
+        bool need = !done && has_body && ticket != 0;
+        bool need_acc = !done && it != 0 && q < count;  // lane q fetches the impulses of contact point q
+        v3 my_acc = zero;
+        uint32_t sweeps = 0;
+        for (;;) {
+            uint32_t gap = 0;
+            if (!done) {
+                u32x4 g, p;
+                if (need) g = ld_granule(rv, body * 32u + (angular ? 16u : 0u));
+                if (need_acc) p = ld_granule(ra, (q * cap + d) * 16u);
+                if (need) {
+                    const uint32_t want = etag | ticket;
+                    if (g.w == want) { x = granule_v3(g); need = false; }
+                    else {
+                        const uint32_t seen = (g.w >> 16) == epoch ? (g.w & 0xFFFFu) : 0u;
+                        gap = ticket > seen ? ticket - seen : 1u;
+                    }
+                }
+                if (need_acc) {
+                    if (p.w == (etag | it)) { my_acc = granule_v3(p); need_acc = false; }
+                    else if (gap == 0) gap = 1;
+                }
+            }
+            // the manifold goes when its four lanes have what they need
+            int ready = (!need && !need_acc) ? 1 : 0;
+            ready &= quad_perm_i<kQuadXor1>(ready);
+            ready &= quad_perm_i<kQuadXor2>(ready);
+            if (!done && ready) {
+                if (it != 0) {  // everybody needs every point's accumulated impulses
+                    pn[0] = quad_perm<0x00>(my_acc.x); pt0[0] = quad_perm<0x00>(my_acc.y); pt1[0] = quad_perm<0x00>(my_acc.z);
+                    pn[1] = quad_perm<0x55>(my_acc.x); pt0[1] = quad_perm<0x55>(my_acc.y); pt1[1] = quad_perm<0x55>(my_acc.z);
+                    pn[2] = quad_perm<0xAA>(my_acc.x); pt0[2] = quad_perm<0xAA>(my_acc.y); pt1[2] = quad_perm<0xAA>(my_acc.z);
+                    pn[3] = quad_perm<0xFF>(my_acc.x); pt0[3] = quad_perm<0xFF>(my_acc.y); pt1[3] = quad_perm<0xFF>(my_acc.z);
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (k < (int)count) {
+#pragma unroll
+                        for (int t = 0; t < 3; ++t) {
+                            // row_velocity: (dir.vB + aB.wB) - (dir.vA + aA.wA), the two sums made inside each pair
+                            const float part = v3_dot(Jv[k][t], x);
+                            const float mine = part + quad_perm<kQuadXor1>(part);
+                            const float other = quad_perm<kQuadXor2>(mine);
+                            const float vrel = side_a ? other - mine : mine - other;
+                            float lambda;
+                            if (t < 2) {  // solve_row_dir, friction
+                                const float mass = t == 0 ? tm0[k] : tm1[k];
+                                float& acc = t == 0 ? pt0[k] : pt1[k];
+                                lambda = -mass * vrel;
+                                const float maxf = friction * pn[k];
+                                const float old = acc;
+                                const float np = det_maxf(-maxf, det_minf(old + lambda, maxf));
+                                lambda = np - old;
+                                acc = np;
+                            } else {      // normal
+                                lambda = nm[k] * (bias[k] - vrel);
+                                const float old = pn[k];
+                                const float np = det_maxf(old + lambda, 0.0f);
+                                lambda = np - old;
+                                pn[k] = np;
+                            }
+                            x = v3_add(x, v3_scale(Rs[k][t], lambda));  // row_apply
+                        }
+                    }
+                }
+                if (has_body) {
+                    if (final_update)
+                        reinterpret_cast<float4*>(vel)[2 * (size_t)body + (angular ? 1 : 0)] = make_float4(x.x, x.y, x.z, keep_w);
+                    else
+                        st_granule(rv, body * 32u + (angular ? 16u : 0u), x, etag | (ticket + 1u));
+                }
+                if (!last_it && q < count) {
+                    const v3 mine = q == 0 ? v3_make(pn[0], pt0[0], pt1[0])
+                                  : q == 1 ? v3_make(pn[1], pt0[1], pt1[1])
+                                  : q == 2 ? v3_make(pn[2], pt0[2], pt1[2]) : v3_make(pn[3], pt0[3], pt1[3]);
+                    st_granule(ra, (q * cap + d) * 16u, mine, etag | (it + 1u));
+                }
+                done = true;
+            }
+            if (__all(done)) break;
+            if (__any(!done && gap <= 1u)) __builtin_amdgcn_s_sleep(1);
+            else if (__any(!done && gap <= 4u)) __builtin_amdgcn_s_sleep(40);
+            else __builtin_amdgcn_s_sleep(127);
+            if ((++sweeps & 63u) == 0u) {
+                const bool dead = (wall_clock64() - t_start > kFlowTimeoutTicks) ||
+                                  (__hip_atomic_load(&ctr->overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 16u);
+                if (dead) {
+                    if ((threadIdx.x & 63u) == 0u) atomicOr(&ctr->overflow, 16u);
+                    done = true;
+                }
+            }
+        }
+    }
+}
+
 // Launch sizes come from the HINT (counters of an earlier step, read back asynchronously); every kernel
 // takes its real ranges from the device-side counters, so a stale hint costs speed, never correctness.
 void launch_solver(phys_world* w, float dt) {
@@ -464,17 +675,18 @@ void launch_solver(phys_world* w, float dt) {
             w->flow_epoch = 1;
         }
         // about one wave per SIMD or less: waiting waves must not crowd out the ones that can run
-        const uint32_t threads = m_hint <= 20000 ? 64u : 256u;
-        uint64_t items = (uint64_t)w->cfg.solver_iterations * ((m_hint * 5 / 4 + threads - 1) / threads) + 1;
-        const uint64_t most = threads == 64 ? 192 : 256;
+        const bool quad = m_hint <= kFlowQuadMaxManifolds;  // four lanes per manifold while the hop latency is everything
+        const uint32_t threads = 256u;
+        const uint32_t rows_per_item = quad ? threads / 4 : threads;
+        uint64_t items = (uint64_t)w->cfg.solver_iterations * ((m_hint * 5 / 4 + rows_per_item - 1) / rows_per_item) + 1;
+        const uint64_t most = quad ? 224 : 256;
         if (items > most) items = most;  // the remaining items are taken by the same workgroups
         PHYS_PROF(w, PHYS_STAGE_SOLVE_FLOW);
-        if (diag)
-            hipLaunchKernelGGL(k_solve_flow<true>, dim3((unsigned)items), dim3(threads), 0, s, w->counters.p, w->cfg.solver_iterations,
-                               w->flow_epoch, rows, sp.friction, inertia, stride, w->vel.p, w->flow_vel.p, (uint32_t)w->n);
-        else
-            hipLaunchKernelGGL(k_solve_flow<false>, dim3((unsigned)items), dim3(threads), 0, s, w->counters.p, w->cfg.solver_iterations,
-                               w->flow_epoch, rows, sp.friction, inertia, stride, w->vel.p, w->flow_vel.p, (uint32_t)w->n);
+#define PHYS_FLOW_LAUNCH(K, D) hipLaunchKernelGGL((K<D>), dim3((unsigned)items), dim3(threads), 0, s, w->counters.p, w->cfg.solver_iterations, \
+                               w->flow_epoch, rows, sp.friction, inertia, stride, w->vel.p, w->flow_vel.p, (uint32_t)w->n)
+        if (quad) { if (diag) PHYS_FLOW_LAUNCH(k_solve_flow_quad, true); else PHYS_FLOW_LAUNCH(k_solve_flow_quad, false); }
+        else { if (diag) PHYS_FLOW_LAUNCH(k_solve_flow, true); else PHYS_FLOW_LAUNCH(k_solve_flow, false); }
+#undef PHYS_FLOW_LAUNCH
         return;
     }
     // colours [0, big) get a launch each; [big, n_colours) go through the single-workgroup tail
