@@ -63,20 +63,27 @@ def stage_bytes(stage, st, iters):
     return 0
 
 
+def _kernel_matches(name, kernel):
+    """Row name of a rocprofv3 table vs a kernel family: k_solve_flow also covers its k_solve_flow_quad variant."""
+    base = name.split("(")[0].split("<")[0].replace("void ", "").strip().split("::")[-1]
+    return base == kernel or base.startswith(kernel + "_")
+
+
 def rocprof_avg_us(workload_key, kernel):
-    """Average kernel duration from the committed rocprofv3 --kernel-trace run of this same script: the per-kernel
-    statistics of the launches of its profile pass (profiles/r1_<workload>_profile_pass_stats.csv, cut out of the
-    trace by tools/trace_tail.py; the whole-run --stats summary is r1_<workload>_kernel_stats.csv). HIP-event
-    brackets (avg_launch_us) additionally contain the dispatch of the launch (about 2-4 us per launch)."""
+    """(kernel name, average duration in us) from the committed rocprofv3 --kernel-trace run of this same script:
+    the per-kernel statistics of the launches of its profile pass (profiles/r1_<workload>_profile_pass_stats.csv,
+    cut out of the trace by tools/trace_tail.py; the whole-run --stats summary is r1_<workload>_kernel_stats.csv).
+    HIP-event brackets (avg_launch_us) additionally contain the dispatch of the launch (about 2-4 us per launch)."""
     import csv
     for name in (f"r1_{workload_key}_profile_pass_stats.csv", f"r1_{workload_key}_kernel_stats.csv"):
         path = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(path):
             continue
-        for row in csv.DictReader(open(path)):
-            if row["Name"].split("(")[0].split("<")[0].endswith(kernel):
-                return round(float(row["AverageNs"]) / 1e3, 3)
-    return None
+        rows = [r for r in csv.DictReader(open(path)) if _kernel_matches(r["Name"], kernel)]
+        if rows:
+            r = max(rows, key=lambda r: int(r["Calls"]))
+            return r["Name"].split("(")[0].replace("void ", "").strip().split("::")[-1], round(float(r["AverageNs"]) / 1e3, 3)
+    return None, None
 
 
 def pmc_traffic(workload_key, kernel):
@@ -86,9 +93,9 @@ def pmc_traffic(workload_key, kernel):
     if not os.path.exists(path):
         return None
     table = json.load(open(path)).get(workload_key, {})
-    for name, row in table.items():
-        if name.split("<")[0].endswith(kernel):
-            return row["traffic_bytes"]
+    rows = [row for name, row in table.items() if isinstance(row, dict) and _kernel_matches(name, kernel)]
+    if rows:
+        return max(rows, key=lambda r: r["launches_sampled"])["traffic_bytes"]
     return None
 
 
@@ -153,11 +160,13 @@ def profile_pass(world, steps, iters, workload_key="c2"):
     dur_s = table[dom]["avg_launch_us"] * 1e-6
     achieved = per_launch / dur_s / 1e9 if dur_s > 0 else 0.0
     total_bytes = sum(stage_bytes(s, st, iters) for s in kernel_stages)
-    roof = {"bound": "hbm", "kernel": KERNEL_OF_STAGE[dom], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+    family = KERNEL_OF_STAGE[dom].split("+")[0]
+    prof_name, prof_us = rocprof_avg_us(workload_key, family)
+    roof = {"bound": "hbm", "kernel": prof_name or KERNEL_OF_STAGE[dom], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-            "traffic": pmc_traffic(workload_key, KERNEL_OF_STAGE[dom].split("+")[0]),
+            "traffic": pmc_traffic(workload_key, family),
             "algorithmic_bytes_per_launch": int(per_launch), "avg_launch_us": round(table[dom]["avg_launch_us"], 3),
-            "avg_kernel_us_rocprofv3": rocprof_avg_us(workload_key, KERNEL_OF_STAGE[dom].split("+")[0]),
+            "avg_kernel_us_rocprofv3": prof_us,
             "launches_per_step": round(launches, 2), "stage_share_of_device_time": round(
                 table[dom]["ms_per_step"] / max(sum(t["ms_per_step"] for t in table.values()), 1e-12), 3),
             "algorithmic_bytes_per_step_all_kernels": int(total_bytes)}
