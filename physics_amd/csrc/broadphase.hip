@@ -142,6 +142,42 @@ __global__ __launch_bounds__(kScanThreads) void k_scan_final(const uint32_t* __r
     }
 }
 
+// small tables (<= 32768 buckets): the whole exclusive scan in ONE workgroup, one launch instead of three
+constexpr int kScanSmallThreads = 1024;
+constexpr int kScanSmallItems = 32;
+__global__ __launch_bounds__(kScanSmallThreads) void k_scan_small(const uint32_t* __restrict__ in, uint32_t count /* multiple of 4 */,
+                                                                  uint32_t* __restrict__ out /*count + 1*/) {
+    __shared__ uint32_t wtot[kScanSmallThreads / 64];
+    const uint32_t base = threadIdx.x * kScanSmallItems;
+    uint4 v[kScanSmallItems / 4];
+    uint32_t sum = 0;
+#pragma unroll
+    for (int k = 0; k < kScanSmallItems / 4; ++k) {
+        v[k] = make_uint4(0u, 0u, 0u, 0u);
+        if (base + 4 * k < count) v[k] = *reinterpret_cast<const uint4*>(in + base + 4 * k);
+        sum += v[k].x + v[k].y + v[k].z + v[k].w;
+    }
+    const uint32_t inc = wave_inclusive_scan(sum);
+    if ((threadIdx.x & 63) == 63) wtot[threadIdx.x >> 6] = inc;
+    __syncthreads();
+    uint32_t run = inc - sum;
+    for (uint32_t k = 0; k < (threadIdx.x >> 6); ++k) run += wtot[k];
+#pragma unroll
+    for (int k = 0; k < kScanSmallItems / 4; ++k) {
+        if (base + 4 * k < count) {
+            uint4 o;
+            o.x = run; o.y = o.x + v[k].x; o.z = o.y + v[k].y; o.w = o.z + v[k].z;
+            *reinterpret_cast<uint4*>(out + base + 4 * k) = o;
+            run = o.w + v[k].w;
+        }
+    }
+    if (threadIdx.x == kScanSmallThreads - 1) {
+        uint32_t total = 0;
+        for (int k = 0; k < kScanSmallThreads / 64; ++k) total += wtot[k];
+        out[count] = total;  // grand total in the extra slot
+    }
+}
+
 // ---- group bodies by bucket -----------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_scatter(uint32_t n, const float* __restrict__ aabb,
                                                  const uint32_t* __restrict__ bucket_of,
@@ -444,7 +480,10 @@ void launch_broadphase(phys_world* w) {
     } else {
     { PHYS_PROF(w, PHYS_STAGE_GRID); hipLaunchKernelGGL(k_cell_assign, gb, tb, 0, s, n, w->aabb.p, w->shape.p, w->counters.p, axis_mask, w->bucket_of.p,
                        w->bucket_cursor.p, w->bucket_count.p); }
-    {
+    if (T <= (uint32_t)(kScanSmallThreads * kScanSmallItems) && T % 4 == 0) {
+        PHYS_PROF(w, PHYS_STAGE_GRID);
+        hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(kScanSmallThreads), 0, s, w->bucket_count.p, T, w->bucket_start.p);
+    } else {
         const uint32_t nblk = (T + kScanChunk - 1) / kScanChunk;
         { PHYS_PROF(w, PHYS_STAGE_GRID); hipLaunchKernelGGL(k_scan_reduce, dim3(nblk), dim3(kScanThreads), 0, s, w->bucket_count.p, T, w->scan_block_sums.p); }
         { PHYS_PROF(w, PHYS_STAGE_GRID); hipLaunchKernelGGL(k_scan_block_sums, dim3(1), dim3(1024), 0, s, w->scan_block_sums.p, nblk); }
