@@ -154,6 +154,13 @@ __device__ __forceinline__ uint32_t stored_manifolds(const StepCounters* ctr, ui
 
 constexpr int kColorThreads = 1024;
 
+// Ordering between the waves of ONE workgroup that talk through global memory (single-workgroup colouring
+// kernels): every wave's stores and atomics have been performed at the L2 once its vmcnt has drained, and the
+// readers load past the L1 (sc1 atomic loads), so draining + the workgroup barrier is all it takes. An
+// agent-scope __threadfence() here would write back and invalidate caches of the whole XCD from all 16 waves
+// (microseconds per round) for data that never leaves this CU's path to its L2.
+__device__ __forceinline__ void drain_stores_for_workgroup() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 // One synchronous Jones-Plassmann round in ONE launch. Three per-body priority buffers rotate:
 //   top      (read)   maxima over the manifolds uncoloured at the start of this round - complete;
 //   top_next (atomic) losers of this round = exactly the manifolds uncoloured at the start of the next
@@ -281,7 +288,7 @@ __global__ __launch_bounds__(kColorThreads) void k_color_finish(uint32_t round, 
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) wins += (uint32_t)__shfl_xor((int)wins, off, 64);
         if ((threadIdx.x & 63) == 0) s_wins[threadIdx.x >> 6] = wins;
-        __threadfence();  // this round's stores and atomics are performed before anyone starts the next
+        drain_stores_for_workgroup();  // this round's stores and atomics are performed before anyone starts the next
         __syncthreads();
         uint32_t t = 0;
         for (int k = 0; k < kColorThreads / 64; ++k) t += s_wins[k];
@@ -488,7 +495,7 @@ __global__ __launch_bounds__(kColorThreads) void k_color_small(uint64_t max_mani
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) wins += (uint32_t)__shfl_xor((int)wins, off, 64);
             if ((threadIdx.x & 63) == 0) s_wins[threadIdx.x >> 6] = wins;
-            __threadfence();  // this round's stores and atomics are performed before anyone starts the next
+            drain_stores_for_workgroup();  // this round's stores and atomics are performed before anyone starts the next
             __syncthreads();
             uint32_t t = 0;
             for (int k = 0; k < kColorThreads / 64; ++k) t += s_wins[k];
@@ -540,7 +547,7 @@ __global__ __launch_bounds__(kColorThreads) void k_color_small(uint64_t max_mani
         }
         if (threadIdx.x == 0) ctr->n_colors = cmax;
     }
-    __threadfence();
+    drain_stores_for_workgroup();
     __syncthreads();
     if (in_regs) {
 #pragma unroll
