@@ -63,6 +63,7 @@ def load():
         "oracle_det_sincos": (None, [f32p, C.c_uint64, f32p, f32p]),
         "oracle_det_asin": (None, [f32p, C.c_uint64, f32p]),
         "oracle_det_atan2": (None, [f32p, f32p, C.c_uint64, f32p]),
+        "oracle_solve_drivers_mismatch": (C.c_int32, [f32p, C.c_int32, C.c_int32, C.c_int32]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -289,6 +290,13 @@ def det_asin(x):
     out = np.empty_like(x)
     load().oracle_det_asin(_p(x), x.size, _p(out))
     return out
+
+
+def solve_drivers_mismatch(flat, count, has_b, iters=8):
+    """Bits that differ between contact_solve.h's two drivers (Jacobians beforehand / on the way) on one manifold."""
+    flat = _f(flat)
+    assert flat.size == 67
+    return int(load().oracle_solve_drivers_mismatch(_p(flat), int(count), int(has_b), int(iters)))
 
 
 def det_atan2(y, x):

@@ -326,4 +326,41 @@ void oracle_det_atan2(const float* y, const float* x, uint64_t n, float* out) {
     for (uint64_t k = 0; k < n; ++k) out[k] = det_atan2f(y[k], x[k]);
 }
 
+// contact_solve.h has two drivers of the row arithmetic (Jacobians made beforehand / on the way); the HIP kernels
+// use both. Runs `iters` sweeps of each on one manifold described by flat arrays; returns the number of output
+// floats whose BITS differ (must be 0). in: normal 3, count, has_b, 4 x (rA 3, rB 3, depth) = 28 floats + invMA,
+// invMB, IA 9, IB 9, vA 3, wA 3, vB 3, wB 3, friction; see tests/test_collide_kat.py.
+int32_t oracle_solve_drivers_mismatch(const float* in, int32_t count, int32_t has_b, int32_t iters) {
+    manifold_t g;
+    g.normal = v3_make(in[0], in[1], in[2]);
+    g.count = count;
+    const float* p = in + 3;
+    v3 xA = v3_make(0.0f, 0.0f, 0.0f), xB = v3_make(p[28], p[29], p[30]);
+    for (int k = 0; k < 4; ++k) { g.pt[k] = v3_make(p[7 * k], p[7 * k + 1], p[7 * k + 2]); g.depth[k] = p[7 * k + 6]; }
+    const float invMA = p[31], invMB = p[32];
+    m33 IA, IB;
+    for (int k = 0; k < 9; ++k) { IA.m[k] = p[33 + k]; IB.m[k] = p[42 + k]; }
+    const float friction = p[63];
+    solve_params_t sp;
+    sp.dt = 0.016666668f; sp.baumgarte = 0.2f; sp.slop = 0.01f; sp.friction = friction; sp.max_bias = 3.0f;
+    solver_manifold_t a, b;
+    solver_prep(&g, has_b, xA, xB, invMA, &IA, invMB, &IB, &sp, &a);
+    b = a;
+    v3 va[4], vb[4];
+    for (int k = 0; k < 4; ++k) va[k] = vb[k] = v3_make(p[51 + 3 * k], p[52 + 3 * k], p[53 + 3 * k]);
+    solver_jac_t J;
+    solver_jacobians(&a, invMA, &IA, invMB, &IB, &J);
+    for (int it = 0; it < iters; ++it) {
+        solve_manifold(&a, &J, friction, &va[0], &va[1], &va[2], &va[3]);
+        solve_manifold_lazy(&b, friction, invMA, &IA, invMB, &IB, &vb[0], &vb[1], &vb[2], &vb[3]);
+    }
+    int32_t bad = 0;
+    for (int k = 0; k < 4; ++k) bad += std::memcmp(&va[k], &vb[k], sizeof(v3)) != 0;
+    for (int k = 0; k < 4; ++k) {
+        bad += std::memcmp(&a.row[k].pn, &b.row[k].pn, 4) != 0;
+        bad += std::memcmp(a.row[k].pt, b.row[k].pt, 8) != 0;
+    }
+    return bad;
+}
+
 }  // extern "C"

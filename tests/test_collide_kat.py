@@ -187,3 +187,23 @@ def test_colouring_is_proper_and_order_independent():
             assert (b, c) not in seen
             seen.add((b, c))
     assert colors.max() + 1 == w.get_stats().n_colors
+
+
+def test_both_solver_drivers_give_the_same_bits():
+    """contact_solve.h drives the same row arithmetic two ways: Jacobians of all rows made beforehand (the
+    dataflow kernels, which make them while they wait) or row by row on the way (the per-colour kernels and the
+    oracle). Random manifolds, full inertia tensors, with and without a second body: not one bit may differ."""
+    from oracle import binding as ob
+    rng = np.random.default_rng(5)
+    for trial in range(300):
+        n = rng.normal(size=3)
+        n /= np.linalg.norm(n)
+        count = int(rng.integers(1, 5))
+        has_b = int(rng.integers(0, 2))
+        pts = np.concatenate([np.concatenate([rng.uniform(-1, 1, 3), rng.uniform(-1, 1, 3), [rng.uniform(-0.02, 0.05)]])
+                              for _ in range(4)])
+        a = rng.normal(scale=0.3, size=(2, 3, 3))
+        inertia = [np.eye(3) * rng.uniform(0.5, 2.0) + m @ m.T for m in a]
+        flat = np.concatenate([n, pts, rng.uniform(-2, 2, 3), rng.uniform(0.3, 2.0, 2), inertia[0].reshape(-1),
+                               inertia[1].reshape(-1), rng.normal(scale=2.0, size=12), [rng.uniform(0.0, 1.0)]])
+        assert ob.solve_drivers_mismatch(flat.astype(np.float32), count, has_b) == 0, trial
