@@ -664,7 +664,9 @@ void launch_solver(phys_world* w, float dt) {
     // the dataflow kernel wins while a colour class is too small to fill the chip (launch / latency bound);
     // beyond that the per-colour launches stream better. Both give the same bits, so the choice may change
     // from step to step.
-    const bool flow = w->flow_vel.p && h.valid && m_hint <= kFlowMaxManifolds && w->cfg.solver_iterations > 0;
+    // (tickets are 16-bit: iterations x 64 colours must stay below 65536)
+    const bool flow = w->flow_vel.p && h.valid && m_hint <= kFlowMaxManifolds && w->cfg.solver_iterations > 0 &&
+                      w->cfg.solver_iterations < 1000;
     { PHYS_PROF(w, PHYS_STAGE_ROWS); hipLaunchKernelGGL(k_rows_build, grid_for_count(m_hint), tb, 0, s, w->counters.p, rows, sp, w->row_src.p, w->man_a.p, w->man_b.p, w->man_count.p,
                        w->man_normal.p, w->man_points.p, w->pos.p, w->vel.p, w->inv_inertia.p, w->man_color.p,
                        w->color_state.p, flow ? 1 : 0); }
