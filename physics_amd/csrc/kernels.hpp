@@ -48,6 +48,39 @@ __device__ __forceinline__ void st_vel(float* __restrict__ vel, uint32_t i, cons
     reinterpret_cast<float4*>(vel)[2 * (size_t)i + 1] = make_float4(r.w.x, r.w.y, r.w.z, r.mass);
 }
 
+// Persistent colouring: hash table (a << 32 | b) -> colour of this update's manifolds, looked up by the next
+// update's narrow phase. Open addressing, linear probing; the table has at least 1.5 slots per manifold SLOT of the
+// world, so an insert always finds room. The layout depends on arrival order, the answers (exact key matches) do
+// not. The job rides along in k_rows_build (launch_coloring fills it in, launch_solver hands it over).
+struct ColorTableJob {
+    unsigned long long* keys;        // null: nothing to do
+    uint32_t* cols;
+    uint32_t mask;
+    uint32_t* slots;                 // [0] = count, then the slot of every manifold (sparse clear two updates later)
+    unsigned long long* other_keys;  // the table the narrow phase of THIS update read: emptied here (null: not yet used)
+    const uint32_t* other_slots;
+    const uint32_t* man_a; const uint32_t* man_b; const uint32_t* man_color; const uint64_t* man_prio;
+};
+
+__device__ __forceinline__ void color_table_update(const ColorTableJob& job, uint32_t M) {
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x, nthreads = gridDim.x * blockDim.x;
+    if (job.other_keys) {
+        // revisit exactly the slots the last build filled: no memset of a capacity-sized table, no extra launch
+        const uint32_t count = job.other_slots[0];
+        for (uint32_t i = tid; i < count; i += nthreads) job.other_keys[job.other_slots[1 + i]] = ~0ull;
+    }
+    if (tid == 0) job.slots[0] = M;
+    for (uint32_t m = tid; m < M; m += nthreads) {
+        const unsigned long long key = ((unsigned long long)job.man_a[m] << 32) | job.man_b[m];
+        uint32_t h = (uint32_t)(job.man_prio[m] >> 20) & job.mask;
+        for (;;) {
+            const unsigned long long prev = atomicCAS(&job.keys[h], ~0ull, key);
+            if (prev == ~0ull || prev == key) { job.cols[h] = job.man_color[m]; job.slots[1 + m] = h; break; }
+            h = (h + 1) & job.mask;
+        }
+    }
+}
+
 // integrate.hip
 void launch_step_full(phys_world* w, float dt, bool gravity);
 void launch_step_velocity_aabb(phys_world* w, float dt, bool gravity, bool zero_step);  // zero_step: also zero the per-step state

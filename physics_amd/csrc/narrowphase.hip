@@ -303,39 +303,6 @@ __global__ __launch_bounds__(kColorThreads) void k_color_finish(uint32_t round, 
     }
 }
 
-// hash table (a << 32 | b) -> colour of this update's manifolds, looked up by the next update's narrow phase.
-// Open addressing, linear probing; the table has at least 1.5 slots per manifold SLOT of the world, so an
-// insert always finds room. The layout depends on arrival order, the answers (exact key matches) do not.
-__global__ __launch_bounds__(256) void k_color_table_build(uint64_t max_manifolds, const uint32_t* __restrict__ man_a,
-                                                           const uint32_t* __restrict__ man_b,
-                                                           const uint32_t* __restrict__ man_color,
-                                                           const uint64_t* __restrict__ man_prio,
-                                                           unsigned long long* __restrict__ keys,
-                                                           uint32_t* __restrict__ cols, uint32_t mask,
-                                                           uint32_t* __restrict__ slots /* [0] = count, then the slots */,
-                                                           unsigned long long* __restrict__ other_keys,
-                                                           const uint32_t* __restrict__ other_slots,
-                                                           const StepCounters* __restrict__ ctr) {
-    // the OTHER table (looked up by this update's narrow phase, rebuilt by the next update) is emptied here by
-    // revisiting exactly the slots its last build filled: no memset of a capacity-sized table, no extra launch
-    if (other_keys) {
-        const uint32_t count = other_slots[0];
-        for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x)
-            other_keys[other_slots[1 + i]] = ~0ull;
-    }
-    const uint32_t M = stored_manifolds(ctr, max_manifolds);
-    if (blockIdx.x == 0 && threadIdx.x == 0) slots[0] = M;
-    for (uint32_t m = blockIdx.x * blockDim.x + threadIdx.x; m < M; m += gridDim.x * blockDim.x) {
-        const unsigned long long key = ((unsigned long long)man_a[m] << 32) | man_b[m];
-        uint32_t h = (uint32_t)(man_prio[m] >> 20) & mask;
-        for (;;) {
-            const unsigned long long prev = atomicCAS(&keys[h], ~0ull, key);
-            if (prev == ~0ull || prev == key) { cols[h] = man_color[m]; slots[1 + m] = h; break; }
-            h = (h + 1) & mask;
-        }
-    }
-}
-
 // ---- colour-major renumbering: counting sort of the manifolds by colour ---------------------------
 // hist (per-workgroup colour histogram) -> offsets (one workgroup scans colour-major) -> place.
 // No global atomics; the order inside a colour is (workgroup, arrival), which nothing depends on.
@@ -664,20 +631,15 @@ void launch_coloring(phys_world* w) {
     {
         // colour table of this update for the next one (the slot it overwrites was read two updates ago)
         const uint32_t tab = (uint32_t)(w->color_epoch & 1);
-        uint64_t tb64 = ((w->hint.valid ? (uint64_t)w->hint.n_manifolds * 5 / 4 : w->max_manifolds) + 255) / 256 + 1;
-        if (tb64 > 2048) tb64 = 2048;
         if (!w->ctab_fresh[tab]) {
             PHYS_PROF(w, PHYS_STAGE_ROWS);
             (void)hipMemsetAsync(w->ctab_keys[tab].p, 0xFF, ((size_t)w->ctab_mask + 1) * 8, s);  // first use of this table
             w->ctab_fresh[tab] = true;
         }
-        const uint32_t other = tab ^ 1u;
-        const bool clear_other = w->ctab_fresh[other];  // it holds the previous update's entries
-        PHYS_PROF(w, PHYS_STAGE_ROWS);
-        hipLaunchKernelGGL(k_color_table_build, dim3((unsigned)tb64), dim3(256), 0, s, w->max_manifolds, w->man_a.p, w->man_b.p,
-                           w->man_color.p, w->man_prio.p, (unsigned long long*)w->ctab_keys[tab].p, w->ctab_cols[tab].p, w->ctab_mask,
-                           w->ctab_slots[tab].p, clear_other ? (unsigned long long*)w->ctab_keys[other].p : nullptr,
-                           w->ctab_slots[other].p, w->counters.p);
+        // the build itself rides along in k_rows_build (launch_solver): one launch less per step
+        w->ctab_job_pending = true;
+        w->ctab_job_tab = tab;
+        w->ctab_job_clear_other = w->ctab_fresh[tab ^ 1u];  // it holds the previous update's entries
         w->ctab_valid = true;
         w->color_epoch++;
     }

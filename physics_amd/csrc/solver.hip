@@ -66,7 +66,14 @@ __global__ __launch_bounds__(256) void k_rows_build(const StepCounters* __restri
                                                     const float* __restrict__ inv_inertia,
                                                     const uint32_t* __restrict__ man_color,
                                                     const unsigned long long* __restrict__ used,
-                                                    int flow /* 1: k_solve_flow runs this step (tickets, no zeroed impulses) */) {
+                                                    int flow /* 1: k_solve_flow runs this step (tickets, no zeroed impulses) */,
+                                                    ColorTableJob table) {
+    {
+        // colour table for the next update's narrow phase: built even when the solve is skipped, or the update after
+        // an overflow would keep colours from a table two updates old
+        const uint32_t raw = ctr->n_manifolds;
+        if (table.keys) color_table_update(table, (uint64_t)raw < rows.cap ? raw : (uint32_t)rows.cap);
+    }
     if (ctr->overflow) return;  // never solve a truncated set; phys_sync / phys_get_stats report it
     const uint32_t M = ctr->n_manifolds;
     const uint64_t cap = rows.cap;
@@ -667,9 +674,21 @@ void launch_solver(phys_world* w, float dt) {
     // (tickets are 16-bit: iterations x 64 colours must stay below 65536)
     const bool flow = w->flow_vel.p && h.valid && m_hint <= kFlowMaxManifolds && w->cfg.solver_iterations > 0 &&
                       w->cfg.solver_iterations < 1000;
+    ColorTableJob table{};
+    if (w->ctab_job_pending) {
+        const uint32_t tab = w->ctab_job_tab, other = tab ^ 1u;
+        table.keys = (unsigned long long*)w->ctab_keys[tab].p;
+        table.cols = w->ctab_cols[tab].p;
+        table.mask = w->ctab_mask;
+        table.slots = w->ctab_slots[tab].p;
+        table.other_keys = w->ctab_job_clear_other ? (unsigned long long*)w->ctab_keys[other].p : nullptr;
+        table.other_slots = w->ctab_slots[other].p;
+        table.man_a = w->man_a.p; table.man_b = w->man_b.p; table.man_color = w->man_color.p; table.man_prio = w->man_prio.p;
+        w->ctab_job_pending = false;
+    }
     { PHYS_PROF(w, PHYS_STAGE_ROWS); hipLaunchKernelGGL(k_rows_build, grid_for_count(m_hint), tb, 0, s, w->counters.p, rows, sp, w->row_src.p, w->man_a.p, w->man_b.p, w->man_count.p,
                        w->man_normal.p, w->man_points.p, w->pos.p, w->vel.p, w->inv_inertia.p, w->man_color.p,
-                       w->color_state.p, flow ? 1 : 0); }
+                       w->color_state.p, flow ? 1 : 0, table); }
     if (flow) {
         if (++w->flow_epoch > 0xFFFFu) {  // tags would repeat: forget every old one
             (void)hipMemsetAsync(w->flow_vel.p, 0, 8 * w->n * sizeof(float), s);

@@ -193,6 +193,9 @@ struct phys_world {
     uint32_t ctab_mask = 0;     // capacity - 1 (power of two >= 1.5 * max_manifolds)
     bool ctab_valid = false;    // a table of the previous update exists
     uint64_t color_epoch = 0;   // updates with collisions since phys_set_bodies
+    bool ctab_job_pending = false;  // launch_coloring prepared a table build for launch_solver's k_rows_build
+    uint32_t ctab_job_tab = 0;      // which of the two tables it fills
+    bool ctab_job_clear_other = false;
     phys::DevBuf<uint32_t> color_block_hist;  // [colour][workgroup] histogram / offsets of the colour sort
     // colouring state
     phys::DevBuf<unsigned long long> color_state;  // 4n: used masks | three rotating per-body priority buffers
