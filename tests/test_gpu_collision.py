@@ -295,3 +295,39 @@ def test_c2_10k_cubes_1000_steps_north_star_tolerance():
             assert (np.abs(a.astype(np.float64) - b) <= tol).all(), f"{name} beyond 1e-4 relative after {250 * (k + 1)} steps"
         _compare_state(w, o, f"C2 step {250 * (k + 1)}")
     assert w.get_stats().n_manifolds > 10000
+
+
+@pytest.mark.parametrize("iterations", [1, 2, 5])
+def test_solver_iteration_counts(iterations):
+    """Tickets of the dataflow solver are iteration * degree + rank: the first and the last iteration are special
+    (plain velocity record in, plain record out), so 1, 2 and 5 iterations exercise what 8 does not."""
+    from physics_amd import scenes
+    sc = scenes.c3(6, 5, 6)
+    sc.solver_iterations = iterations
+    w, o = _run_scene(sc, 200, 50)
+    assert w.get_stats().n_manifolds > 100
+
+
+def test_one_lane_dataflow_kernel_with_full_inertia_tensors():
+    """More than 24k manifolds AND non-diagonal inertia tensors: k_solve_flow<false> (the general instance of the
+    one-lane-per-manifold dataflow kernel), which no benchmark scene reaches."""
+    import physics_amd
+    from physics_amd import scenes
+    sc = scenes.c5(12, 60, 12)
+    rng = np.random.default_rng(21)
+    n = sc.n
+    a = rng.normal(scale=0.15, size=(n, 3, 3))
+    inertia = (np.eye(3)[None] * rng.uniform(0.6, 1.5, size=(n, 1, 1)) + a @ a.transpose(0, 2, 1)).astype(np.float32)
+    mass = rng.uniform(0.7, 1.4, size=n).astype(np.float32)
+    w, o = _worlds(sc.config)
+    for x in (w, o):
+        x.set_bodies(sc.pos, mass=mass, inertia=inertia.reshape(n, 9), shape_type=sc.shape_type, half_extent=sc.half_extent)
+    for k in range(3):
+        w.update_n(DT, 8)
+        o.update_n(DT, 8)
+        w.sync()
+        _compare_state(w, o, f"tower with full inertia, step {8 * (k + 1)}")
+    assert w.get_stats().n_manifolds > 24000
+    w.profile_enable(True)
+    w.update_n(DT, 2)
+    assert "solve_flow" in w.profile_get()[0]
