@@ -2,6 +2,7 @@
 # One call for the round's evidence: GPU test suite, profiles (tools/profile_all.sh), the default bench line and
 # the other scenes.
 set -e
+timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
 timeout -k 10 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
 ./tools/profile_all.sh
 timeout -k 10 900 python bench.py > gpurun_out/bench_final.log 2>&1
