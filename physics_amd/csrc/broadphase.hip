@@ -5,7 +5,7 @@
 //   1. k_cell_assign   body -> cell of a uniform grid whose cell edge is the largest AABB extent of the
 //                      step (x1.001), cell -> bucket by 3-D Morton interleave of the low cell bits
 //                      (neighbouring cells = neighbouring buckets = neighbouring memory), count per bucket.
-//   2. exclusive scan  bucket counts -> bucket starts (3 small kernels).
+//   2. exclusive scan  bucket counts -> bucket starts (one launch up to 32768 buckets, else 3 small kernels).
 //   3. k_scatter       bodies grouped by bucket: ids + a bucket-ordered COPY of the AABBs (24 B each), so
 //                      the pair kernel streams candidates instead of gathering them.
 //   4. k_find_pairs    one lane per body (bucket order), half shell of 14 cells; overlap test; hits are

@@ -4,10 +4,12 @@
 //
 // k_narrowphase: one lane per work item (ground test of a body, or one candidate pair); manifolds are
 //   compacted per workgroup (wavefront ballot + popcount prefix, wave totals through LDS, ONE global
-//   atomic per workgroup) and written as 88-byte records. Emission order is arbitrary.
-// colouring: synchronous Jones-Plassmann rounds on the line graph. Each round is two kernels
-//   (k_color_top: u64 atomicMax of priorities per body; k_color_assign: winners take the lowest free
-//   colour). max / or are order-independent, so the colours are a pure function of the manifold SET.
+//   atomic per workgroup) and written as 100-byte records. Emission order is arbitrary. A manifold that
+//   existed in the previous update keeps its colour (hash-table probe); the others publish round 0 of the colouring.
+// colouring: synchronous Jones-Plassmann rounds on the line graph over the NEW manifolds, one launch per round
+//   (k_color_round, three rotating per-body priority buffers) + k_color_finish, or everything including the
+//   colour-major sort in one workgroup for small scenes (k_color_small). max / or are order-independent, so the
+//   colours are a pure function of (previous colouring, manifold SET).
 // Algorithmic bytes: per pair 8 + 2 x 44 (pos 12, rot 16, half 12, shape 4) = 96 B read;
 //   per manifold 100 B written (ids 8, count 4, normal 12, points 64, priority 8, colour 4).
 #include "kernels.hpp"
