@@ -173,6 +173,9 @@ __device__ __forceinline__ void drain_stores_for_workgroup() { asm volatile("s_w
 template <bool BYPASS_L1>
 __device__ __forceinline__ uint32_t color_round_lanes(uint32_t first, uint32_t stride, uint32_t M,
                                                       const uint32_t* list /* null: every manifold; else M ids */,
+                                                      uint32_t* next_list /* non-null: `list` holds uncoloured ids only, and
+                                                                             the losers of this round are appended here */,
+                                                      uint32_t* next_count,
                                                       const uint32_t* __restrict__ man_a, const uint32_t* __restrict__ man_b,
                                                       uint32_t* __restrict__ man_color, const uint64_t* __restrict__ man_prio,
                                                       const unsigned long long* top, unsigned long long* top_next,
@@ -181,7 +184,7 @@ __device__ __forceinline__ uint32_t color_round_lanes(uint32_t first, uint32_t s
     uint32_t wins = 0;
     for (uint32_t i = first; i < M; i += stride) {
         const uint32_t m = list ? list[i] : i;
-        if (man_color[m] != kUncolored) continue;
+        if (!next_list && man_color[m] != kUncolored) continue;
         const unsigned long long p = man_prio[m];
         const uint32_t a = man_a[m], b = man_b[m];
         const bool gb = b == PHYS_GROUND_ID;
@@ -210,6 +213,7 @@ __device__ __forceinline__ uint32_t color_round_lanes(uint32_t first, uint32_t s
             man_color[m] = c;
             ++wins;
         } else {
+            if (next_list) next_list[atomicAdd(next_count, 1u)] = m;
             atomicMax(&top_next[a], p);
             if (BYPASS_L1) __hip_atomic_store(&top_clr[a], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else top_clr[a] = 0ull;
             if (!gb) {
@@ -245,7 +249,7 @@ __global__ __launch_bounds__(kColorThreads) void k_color_round(uint32_t round, u
     __syncthreads();
     if (s_uncolored == 0) return;
     const uint32_t M = stored_manifolds(ctr, max_manifolds);
-    uint32_t wins = color_round_lanes<false>(blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x, M, nullptr, man_a, man_b,
+    uint32_t wins = color_round_lanes<false>(blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x, M, nullptr, nullptr, nullptr, man_a, man_b,
                                              man_color, man_prio, top, top_next, top_clr, used, ctr);
     // ONE global atomic per workgroup (same-address atomics serialise chip-wide at ~88 per microsecond)
 #pragma unroll
@@ -285,7 +289,7 @@ __global__ __launch_bounds__(kColorThreads) void k_color_finish(uint32_t round, 
         unsigned long long* top = state + (1 + round % 3) * n;
         unsigned long long* top_next = state + (1 + (round + 1) % 3) * n;
         unsigned long long* top_clr = state + (1 + (round + 2) % 3) * n;
-        uint32_t wins = color_round_lanes<true>(threadIdx.x, kColorThreads, M, nullptr, man_a, man_b, man_color, man_prio, top,
+        uint32_t wins = color_round_lanes<true>(threadIdx.x, kColorThreads, M, nullptr, nullptr, nullptr, man_a, man_b, man_color, man_prio, top,
                                                 top_next, top_clr, used, ctr);
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) wins += (uint32_t)__shfl_xor((int)wins, off, 64);
@@ -404,7 +408,7 @@ __global__ __launch_bounds__(1024) void k_color_place(uint64_t max_manifolds, co
 // Jones-Plassmann round (over a list of the uncoloured manifolds gathered into LDS: with persistent colouring
 // only the new ones), the colour-major counting sort, and the snapshot of the counters into pinned host memory
 // (the launch-size hints of later steps) - instead of ~3 round launches + finish + sort + a copy.
-constexpr int kSmallList = 8192;
+constexpr int kSmallList = 6144;  // ids per list; two lists: the uncoloured of this round / of the next
 constexpr int kSmallTrips = 24;  // manifolds per thread kept in registers: 24 x 1024 = the `small` limit of launch_coloring
 __global__ __launch_bounds__(kColorThreads) void k_color_small(uint64_t max_manifolds, const uint32_t* __restrict__ man_a,
                                                               const uint32_t* __restrict__ man_b, uint32_t* man_color,
@@ -412,7 +416,8 @@ __global__ __launch_bounds__(kColorThreads) void k_color_small(uint64_t max_mani
                                                               unsigned long long* __restrict__ state /*4n*/, uint64_t n,
                                                               uint32_t* __restrict__ row_src, StepCounters* ctr,
                                                               StepCounters* snap_out /* host-mapped, may be null */) {
-    __shared__ uint32_t s_list[kSmallList];
+    __shared__ uint32_t s_list[2][kSmallList];
+    __shared__ uint32_t s_cnt[2];
     __shared__ uint32_t s_n, s_left;
     __shared__ uint32_t s_wins[kColorThreads / 64];
     __shared__ uint32_t h[PHYS_MAX_COLORS], cursor[PHYS_MAX_COLORS];
@@ -438,29 +443,38 @@ __global__ __launch_bounds__(kColorThreads) void k_color_small(uint64_t max_mani
             for (int k = 0; k < kSmallTrips; ++k) {
                 if (col[k] == kUncolored) {
                     const uint32_t at = atomicAdd(&s_n, 1u);
-                    if (at < (uint32_t)kSmallList) s_list[at] = k * kColorThreads + threadIdx.x;
+                    if (at < (uint32_t)kSmallList) s_list[0][at] = k * kColorThreads + threadIdx.x;
                 }
             }
         } else {
             for (uint32_t m = threadIdx.x; m < M; m += kColorThreads) {
                 if (man_color[m] == kUncolored) {
                     const uint32_t at = atomicAdd(&s_n, 1u);
-                    if (at < (uint32_t)kSmallList) s_list[at] = m;
+                    if (at < (uint32_t)kSmallList) s_list[0][at] = m;
                 }
             }
         }
         __syncthreads();
-        const bool listed = s_n <= (uint32_t)kSmallList;
-        const uint32_t* list = listed ? s_list : nullptr;
-        const uint32_t count = listed ? s_n : M;
+        // The rounds run over a LIST of the uncoloured manifolds that shrinks with every round (the losers of a round
+        // are the list of the next one). A full re-colouring starts with more than a list holds: it scans all
+        // manifolds until few enough are left.
+        bool listed = s_n <= (uint32_t)kSmallList;
+        uint32_t cur = 0;
+        if (threadIdx.x == 0) s_cnt[0] = s_n;
         unsigned long long* used = state;
         uint32_t round = 0;
         while (left != 0) {
             unsigned long long* top = state + (1 + round % 3) * n;
             unsigned long long* top_next = state + (1 + (round + 1) % 3) * n;
             unsigned long long* top_clr = state + (1 + (round + 2) % 3) * n;
-            uint32_t wins = color_round_lanes<true>(threadIdx.x, kColorThreads, count, list, man_a, man_b, man_color, man_prio,
-                                                    top, top_next, top_clr, used, ctr);
+            const uint32_t nxt = cur ^ 1u;
+            if (threadIdx.x == 0) s_cnt[nxt] = 0;
+            __syncthreads();
+            uint32_t wins = listed
+                ? color_round_lanes<true>(threadIdx.x, kColorThreads, s_cnt[cur], s_list[cur], s_list[nxt], &s_cnt[nxt], man_a, man_b,
+                                          man_color, man_prio, top, top_next, top_clr, used, ctr)
+                : color_round_lanes<true>(threadIdx.x, kColorThreads, M, nullptr, nullptr, nullptr, man_a, man_b, man_color,
+                                          man_prio, top, top_next, top_clr, used, ctr);
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) wins += (uint32_t)__shfl_xor((int)wins, off, 64);
             if ((threadIdx.x & 63) == 0) s_wins[threadIdx.x >> 6] = wins;
@@ -470,8 +484,20 @@ __global__ __launch_bounds__(kColorThreads) void k_color_small(uint64_t max_mani
             for (int k = 0; k < kColorThreads / 64; ++k) t += s_wins[k];
             left -= t;
             ++round;
-            __syncthreads();
             if (t == 0) break;  // cannot happen (the highest priority always wins); never spin
+            if (listed) {
+                cur = nxt;
+            } else if (left != 0 && left <= (uint32_t)kSmallList) {
+                // few enough are left: list them (each thread looks at the manifolds it has been handling itself)
+                if (threadIdx.x == 0) s_cnt[0] = 0;
+                __syncthreads();
+                for (uint32_t m = threadIdx.x; m < M; m += kColorThreads)
+                    if (__hip_atomic_load(&man_color[m], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == kUncolored)
+                        s_list[0][atomicAdd(&s_cnt[0], 1u)] = m;
+                listed = true;
+                cur = 0;
+            }
+            __syncthreads();
         }
         if (threadIdx.x == 0) {
             ctr->n_uncolored = left;
