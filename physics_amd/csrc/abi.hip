@@ -157,10 +157,10 @@ int32_t phys_destroy(phys_world* w) {
     DevBuf<float>* fb[] = {&w->pos, &w->rot, &w->vel, &w->force, &w->torque, &w->inv_inertia_diag,
                            &w->inv_inertia, &w->half_extent, &w->aabb, &w->cg_x, &w->cg_r, &w->cg_p, &w->cg_ap,
                            &w->cg_rhs, &w->cg_c, &w->cg_scratch, &w->man_normal, &w->man_points, &w->row_n,
-                           &w->row_pt, &w->row_tb, &w->row_acc, &w->flow_vel, &w->sorted_box};
+                           &w->row_pt, &w->row_tb, &w->row_acc, &w->flow_vel, &w->sorted_box, &w->slot_box};
     for (auto* b : fb) b->free();
     DevBuf<uint32_t>* ub[] = {&w->shape, &w->global_id, &w->cg_status, &w->bucket_of, &w->bucket_count,
-                              &w->bucket_start, &w->bucket_cursor, &w->sorted_ids, &w->scan_block_sums, &w->pairs,
+                              &w->bucket_start, &w->bucket_cursor, &w->sorted_ids, &w->slot_ids, &w->grid_ovf, &w->scan_block_sums, &w->pairs,
                               &w->man_a, &w->man_b, &w->man_count, &w->man_color, &w->row_hdr,
                               &w->row_src, &w->cross_pairs, &w->color_block_hist, &w->cg_cols};
     for (auto* b : ub) b->free();
@@ -195,6 +195,7 @@ int32_t phys_set_bodies(phys_world* w, uint64_t n, const float* pos, const float
     w->have_lambda = false;  // previous_solution: None
     w->aabbs_valid = false;
     w->grid_valid = false;
+    w->sorted_grid_valid = false;
     w->hint = StepHint();
     for (int k = 0; k < phys_world::kSnapRing; ++k) w->snap_pending[k] = false;  // the stream was synchronised above
     if (n == 0) return PHYS_OK;

@@ -388,6 +388,126 @@ __global__ __launch_bounds__(kPairThreads) void k_find_pairs(const uint32_t* __r
     stage_flush(st, pairs, max_pairs, ctr);
 }
 
+// ---- slot grid (small scenes) ------------------------------------------------------------------------
+// With a table of >= 2 buckets per body almost every bucket holds 0-2 bodies: instead of counting, scanning and
+// scattering (three dependent launches) a body simply takes one of EIGHT slots of its bucket (id + box) and the
+// pair kernel reads the neighbours' slots directly. A body that finds the eight slots taken goes to a short overflow list that every body also tests against, so the pair SET is the same as with the
+// sorted grid whatever the occupancy; only the speed depends on it.
+constexpr uint32_t kSlotsPerBucket = 8;
+constexpr uint32_t kSlotGridMaxBodies = 16384;
+
+__global__ __launch_bounds__(256) void k_cell_insert(uint32_t n, const float* __restrict__ aabb,
+                                                     const uint32_t* __restrict__ shape, StepCounters* __restrict__ ctr,
+                                                     uint32_t axis_mask, uint32_t* __restrict__ rank,
+                                                     uint32_t* __restrict__ bucket_count, uint32_t* __restrict__ slot_ids,
+                                                     float* __restrict__ slot_box, uint32_t* __restrict__ ovf) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || shape[i] == PHYS_SPEC_SHAPE_NONE) return;
+    const float inv_cell = grid_inv_cell(ctr);
+    const v3 lo = ld3(aabb, 2 * i), hi = ld3(aabb, 2 * i + 1);
+    const int cx = cell_coord(0.5f * (lo.x + hi.x), inv_cell);
+    const int cy = cell_coord(0.5f * (lo.y + hi.y), inv_cell);
+    const int cz = cell_coord(0.5f * (lo.z + hi.z), inv_cell);
+    const uint32_t bk = bucket_of_cell(cx, cy, cz, axis_mask);
+    const uint32_t r = atomicAdd(&bucket_count[bk], 1u);  // which slot is irrelevant downstream
+    rank[i] = r;
+    if (r < kSlotsPerBucket) {
+        // id AND box go into the slot: the pair kernel then needs no gather by id behind the slot record
+        slot_ids[kSlotsPerBucket * bk + r] = i;
+        st3(slot_box, 2 * (kSlotsPerBucket * bk + r), lo);
+        st3(slot_box, 2 * (kSlotsPerBucket * bk + r) + 1, hi);
+    } else {
+        ovf[atomicAdd(&ctr->n_grid_ovf, 1u)] = i;
+    }
+}
+
+template <int kLanesPerBody>
+__global__ __launch_bounds__(kPairThreads) void k_find_pairs_slots(uint32_t n, const float* __restrict__ aabb,
+                                                                   const uint32_t* __restrict__ shape,
+                                                                   const uint32_t* __restrict__ rank,
+                                                                   const uint32_t* __restrict__ bucket_count,
+                                                                   const uint32_t* __restrict__ slot_ids,
+                                                                   const float* __restrict__ slot_box,
+                                                                   const uint32_t* __restrict__ ovf, uint32_t axis_mask,
+                                                                   uint32_t* __restrict__ pairs, uint64_t max_pairs,
+                                                                   StepCounters* __restrict__ ctr) {
+    constexpr int kCellsPerLane = (14 + kLanesPerBody - 1) / kLanesPerBody;
+    __shared__ uint32_t stage[(kPairThreads / 64) * kStagePerWave * 2];
+    PairStage st;
+    st.lds = stage + (threadIdx.x >> 6) * kStagePerWave * 2;
+    st.count = 0;
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t i = g / kLanesPerBody;
+    const uint32_t sub = g % kLanesPerBody;
+    const bool live = i < n && shape[i] != PHYS_SPEC_SHAPE_NONE;
+    const float inv_cell = grid_inv_cell(ctr);
+    aabb_t bi;
+    bi.lo = v3_make(0, 0, 0); bi.hi = v3_make(0, 0, 0);
+    int cx = 0, cy = 0, cz = 0;
+    bool in_overflow = false;
+    if (live) {
+        bi.lo = ld3(aabb, 2 * i);
+        bi.hi = ld3(aabb, 2 * i + 1);
+        cx = cell_coord(0.5f * (bi.lo.x + bi.hi.x), inv_cell);
+        cy = cell_coord(0.5f * (bi.lo.y + bi.hi.y), inv_cell);
+        cz = cell_coord(0.5f * (bi.lo.z + bi.hi.z), inv_cell);
+        in_overflow = rank[i] >= kSlotsPerBucket;
+    }
+    // half shell: own cell (c = 0) + the 13 cells with (dz, dy, dx) > (0, 0, 0) lexicographically. A body of the
+    // overflow list looks at nobody's slots: its pairs come from the others' (and its own) pass over that list.
+    uint32_t cnt[kCellsPerLane], first[kCellsPerLane];
+#pragma unroll
+    for (int k = 0; k < kCellsPerLane; ++k) {
+        const int c = (int)sub + kLanesPerBody * k;
+        int dx, dy, dz;
+        if (c == 0) { dx = 0; dy = 0; dz = 0; }
+        else if (c == 1) { dx = 1; dy = 0; dz = 0; }
+        else if (c < 5) { dx = c - 3; dy = 1; dz = 0; }
+        else { dx = (c - 5) % 3 - 1; dy = ((c - 5) / 3) % 3 - 1; dz = 1; }
+        cnt[k] = 0; first[k] = 0;
+        if (live && !in_overflow && c < 14) {
+            const uint32_t bk = bucket_of_cell(cx + dx, cy + dy, cz + dz, axis_mask);
+            const uint32_t have = bucket_count[bk];
+            first[k] = kSlotsPerBucket * bk;
+            cnt[k] = have < kSlotsPerBucket ? have : kSlotsPerBucket;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < kCellsPerLane; ++k) {
+        const bool own_cell = (sub == 0 && k == 0);
+        for (uint32_t r = 0; __any(r < cnt[k]); ++r) {
+            bool hit = false;
+            uint32_t j = 0;
+            if (r < cnt[k]) {
+                const uint32_t slot = first[k] + r;
+                j = slot_ids[slot];
+                aabb_t bj;
+                bj.lo = ld3(slot_box, 2 * slot);
+                bj.hi = ld3(slot_box, 2 * slot + 1);
+                // own cell: each unordered pair once by id order. Other cells: a bucket can alias a far cell
+                // (wrap-around); such a candidate fails the overlap test, and the 14 buckets are distinct.
+                hit = aabb_overlap(bi, bj) && (!own_cell || i < j);
+            }
+            stage_push(st, hit, i < j ? i : j, i < j ? j : i, pairs, max_pairs, ctr);
+        }
+    }
+    // everybody against the overflow list: a slotted body takes every overflow body it overlaps, two overflow
+    // bodies meet once (by id order)
+    const uint32_t n_ovf = ctr->n_grid_ovf;
+    for (uint32_t o = 0; o < n_ovf; ++o) {
+        const uint32_t j = ovf[o];
+        bool hit = false;
+        if (live && sub == 0 && j != i && (!in_overflow || i < j)) {
+            aabb_t bj;
+            bj.lo = ld3(aabb, 2 * j);
+            bj.hi = ld3(aabb, 2 * j + 1);
+            hit = aabb_overlap(bi, bj);
+        }
+        stage_push(st, hit, i < j ? i : j, i < j ? j : i, pairs, max_pairs, ctr);
+    }
+    stage_flush(st, pairs, max_pairs, ctr);
+}
+
 // ---- host side -------------------------------------------------------------------------------------
 static uint32_t table_size_for(uint64_t n) {
     uint32_t t = 512;  // 8^3
@@ -424,6 +544,10 @@ int32_t collision_alloc(phys_world* w) {
     PHYS_HIP_TRY(w->bucket_start.resize((size_t)T + 1));
     PHYS_HIP_TRY(w->scan_block_sums.resize((T + kScanChunk - 1) / kScanChunk + 1));
     PHYS_HIP_TRY(w->sorted_ids.resize(n));
+    PHYS_HIP_TRY(w->slot_ids.resize((size_t)kSlotsPerBucket * T));
+    PHYS_HIP_TRY(w->slot_box.resize((size_t)6 * kSlotsPerBucket * T));
+    PHYS_HIP_TRY(w->grid_ovf.resize(n));
+    w->sorted_grid_valid = false;
     PHYS_HIP_TRY(w->sorted_box.resize(6 * n));
     PHYS_HIP_TRY(w->pairs.resize(2 * w->max_pairs));
     if (!(w->cfg.flags & PHYS_FLAG_BROADPHASE_ONLY)) {
@@ -463,21 +587,26 @@ void zero_step_state(phys_world* w, bool including_extent) {
     (void)hipMemsetAsync(w->step_zero.p, 0, including_extent ? w->step_zero_full_bytes : w->step_zero_reset_bytes, w->stream);
 }
 
-void launch_broadphase(phys_world* w) {
-    const uint32_t n = (uint32_t)w->n;
-    if (n == 0) return;
-    w->grid_valid = true;
-    const uint32_t T = w->grid_table_size;
+static uint32_t grid_axis_mask(const phys_world* w) {
     uint32_t bits = 0;
-    while ((1u << (3 * bits)) < T) ++bits;
-    const uint32_t axis_mask = (1u << bits) - 1u;
+    while ((1u << (3 * bits)) < w->grid_table_size) ++bits;
+    return (1u << bits) - 1u;
+}
+
+// bucket_start / sorted_ids / sorted_box from the current AABBs; the bucket counts must be zero
+void build_sorted_grid(phys_world* w) {
+    const uint32_t n = (uint32_t)w->n;
+    const uint32_t T = w->grid_table_size;
+    const uint32_t axis_mask = grid_axis_mask(w);
     hipStream_t s = w->stream;
     const dim3 gb((n + 255) / 256), tb(256);
+    w->sorted_grid_valid = true;
     if (n <= (uint32_t)(kGridSmallBodies * kGridSmallThreads) && T <= (uint32_t)(kGridSmallBuckets * kGridSmallThreads) && T % 8 == 0) {
         PHYS_PROF(w, PHYS_STAGE_GRID);
         hipLaunchKernelGGL(k_grid_small, dim3(1), dim3(kGridSmallThreads), 0, s, n, w->aabb.p, w->shape.p, w->counters.p, axis_mask, T,
                            w->bucket_count.p, w->bucket_start.p, w->sorted_ids.p, w->sorted_box.p);
-    } else {
+        return;
+    }
     { PHYS_PROF(w, PHYS_STAGE_GRID); hipLaunchKernelGGL(k_cell_assign, gb, tb, 0, s, n, w->aabb.p, w->shape.p, w->counters.p, axis_mask, w->bucket_of.p,
                        w->bucket_cursor.p, w->bucket_count.p); }
     if (T <= (uint32_t)(kScanSmallThreads * kScanSmallItems) && T % 4 == 0) {
@@ -492,7 +621,27 @@ void launch_broadphase(phys_world* w) {
     }
     { PHYS_PROF(w, PHYS_STAGE_GRID); hipLaunchKernelGGL(k_scatter, gb, tb, 0, s, n, w->aabb.p, w->bucket_of.p, w->bucket_cursor.p, w->bucket_start.p,
                        w->sorted_ids.p, w->sorted_box.p); }
+}
+
+void launch_broadphase(phys_world* w) {
+    const uint32_t n = (uint32_t)w->n;
+    if (n == 0) return;
+    w->grid_valid = true;
+    const uint32_t T = w->grid_table_size;
+    const uint32_t axis_mask = grid_axis_mask(w);
+    hipStream_t s = w->stream;
+    if (!w->want_sorted_grid && n <= kSlotGridMaxBodies) {
+        // slot grid: two launches for the whole broad phase
+        w->sorted_grid_valid = false;
+        { PHYS_PROF(w, PHYS_STAGE_GRID); hipLaunchKernelGGL(k_cell_insert, dim3((n + 255) / 256), dim3(256), 0, s, n, w->aabb.p, w->shape.p, w->counters.p,
+                           axis_mask, w->bucket_cursor.p, w->bucket_count.p, w->slot_ids.p, w->slot_box.p, w->grid_ovf.p); }
+        PHYS_PROF(w, PHYS_STAGE_PAIRS);
+        hipLaunchKernelGGL((k_find_pairs_slots<4>), dim3((unsigned)(((uint64_t)n * 4 + kPairThreads - 1) / kPairThreads)), dim3(kPairThreads), 0, s,
+                           n, w->aabb.p, w->shape.p, w->bucket_cursor.p, w->bucket_count.p, w->slot_ids.p, w->slot_box.p, w->grid_ovf.p, axis_mask,
+                           w->pairs.p, w->max_pairs, w->counters.p);
+        return;
     }
+    build_sorted_grid(w);
     // small scenes are latency-bound: 4 lanes per body shorten the dependent chain; large scenes are
     // throughput-bound: one lane per body does the least total work
     if (n <= 200000u) {

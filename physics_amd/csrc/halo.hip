@@ -183,6 +183,13 @@ int32_t halo_pairs(phys_world* w, const void* dev_remote, uint64_t n_remote, uin
                    uint64_t* n_cross) {
     if (n_remote && !dev_remote) { set_error("null argument"); return PHYS_ERR_INVALID_ARG; }
     if (!w->grid_valid) { set_error("phys_halo_pairs needs the grid of an update or phys_broadphase first"); return PHYS_ERR_UNSUPPORTED; }
+    if (!w->sorted_grid_valid) {
+        // the last broad phase used the slot grid of small scenes: build the sorted one from the same AABBs now, and
+        // from now on with every broad phase (this world takes part in a halo exchange)
+        PHYS_HIP_TRY(hipMemsetAsync(w->bucket_count.p, 0, (size_t)w->grid_table_size * 4, w->stream));
+        build_sorted_grid(w);
+        w->want_sorted_grid = true;
+    }
     if (w->max_cross_pairs == 0) {
         w->max_cross_pairs = std::max<uint64_t>(4 * w->n, 4096);
         PHYS_HIP_TRY(w->cross_pairs.resize(2 * w->max_cross_pairs));

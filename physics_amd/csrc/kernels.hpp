@@ -94,6 +94,7 @@ void launch_instance_matrices(phys_world* w, float* d_out);
 int32_t collision_alloc(phys_world* w);
 void zero_step_state(phys_world* w, bool including_extent);  // ONE memset: counters + bucket counts + colouring state
 void launch_broadphase(phys_world* w);
+void build_sorted_grid(phys_world* w);  // bucket_start / sorted_ids / sorted_box from the current AABBs (bucket counts zeroed)
 int32_t sorted_pairs_to_host(phys_world* w, uint32_t* pairs_out, uint64_t cap, uint64_t* n_pairs);
 
 // narrowphase.hip / solver.hip

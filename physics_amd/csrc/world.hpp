@@ -67,6 +67,7 @@ struct StepCounters {
     uint32_t n_cross_pairs;
     uint32_t n_ground_manifolds;
     uint32_t flow_ticket;    // k_solve_flow: next (iteration, row chunk) item to hand to a workgroup
+    uint32_t n_grid_ovf;     // slot grid: bodies that found their bucket's four slots taken
     uint32_t color_count[kMaxColors];  // manifolds per colour
     uint32_t color_start[kMaxColors + 1];
     // LAST member: survives the per-step reset (only the bytes before it are zeroed), so a wave issues the
@@ -176,6 +177,11 @@ struct phys_world {
     phys::DevBuf<phys::StepCounters> counters;
     phys::DevBuf<uint32_t> bucket_of;    // n
     phys::DevBuf<uint32_t> bucket_count, bucket_start, bucket_cursor;  // table
+    phys::DevBuf<uint32_t> slot_ids;     // 4 per bucket: the slot grid of small scenes (no scan, no scatter)
+    phys::DevBuf<float> slot_box;        // the AABB next to every id slot (6 floats)
+    phys::DevBuf<uint32_t> grid_ovf;     // n: bodies beyond the fourth of their bucket
+    bool sorted_grid_valid = false;      // bucket_start / sorted_ids / sorted_box describe the last broad phase
+    bool want_sorted_grid = false;       // a halo exchange uses this world: always build the sorted grid
     phys::DevBuf<uint32_t> sorted_ids;   // n: body ids grouped by bucket
     phys::DevBuf<float> sorted_box;      // 6n: AABBs in bucket order (streamed by the pair kernel)
     phys::DevBuf<uint32_t> scan_block_sums;
