@@ -630,7 +630,7 @@ void launch_broadphase(phys_world* w) {
     const uint32_t T = w->grid_table_size;
     const uint32_t axis_mask = grid_axis_mask(w);
     hipStream_t s = w->stream;
-    if (!w->want_sorted_grid && n <= kSlotGridMaxBodies) {
+    if (n <= kSlotGridMaxBodies) {
         // slot grid: two launches for the whole broad phase
         w->sorted_grid_valid = false;
         { PHYS_PROF(w, PHYS_STAGE_GRID); hipLaunchKernelGGL(k_cell_insert, dim3((n + 255) / 256), dim3(256), 0, s, n, w->aabb.p, w->shape.p, w->counters.p,

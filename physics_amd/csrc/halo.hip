@@ -74,11 +74,34 @@ __global__ __launch_bounds__(256) void k_halo_pack(uint32_t n, const float* __re
     }
 }
 
+// every lane of the wave calls this together: the hits are appended with one atomic per wave
+__device__ __forceinline__ void emit_cross_pairs(bool hit, uint32_t j, uint32_t rgid, uint32_t* __restrict__ cross_pairs,
+                                                 uint64_t cap, StepCounters* __restrict__ ctr) {
+    const int lane = threadIdx.x & 63;
+    const unsigned long long mask = __ballot(hit);
+    if (mask) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(&ctr->n_cross_pairs, (uint32_t)__popcll(mask));
+        base = (uint32_t)__shfl((int)base, 0, 64);
+        if (hit) {
+            const uint64_t slot = (uint64_t)base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+            if (slot < cap) { cross_pairs[2 * slot] = j; cross_pairs[2 * slot + 1] = rgid; }
+            else atomicOr(&ctr->overflow, 8u);
+        }
+    }
+}
+
+// SLOTS: the last broad phase built the slot grid of small scenes (broadphase.hip): `bucket_start` then holds the
+// bucket COUNTS, ids / boxes are the slot arrays (kSlots per bucket), and bodies of the overflow list are tested
+// against every record directly.
+constexpr uint32_t kSlots = 8;  // == kSlotsPerBucket of broadphase.hip
+template <bool SLOTS>
 __global__ __launch_bounds__(256) void k_halo_pairs(uint32_t n_remote, uint32_t skip_first, uint32_t skip_count,
                                                     const HaloRecord* __restrict__ remote,
                                                     const uint32_t* __restrict__ bucket_start, uint32_t table_size,
                                                     uint32_t axis_mask, const uint32_t* __restrict__ sorted_ids,
                                                     const float* __restrict__ sorted_box,
+                                                    const uint32_t* __restrict__ ovf, const float* __restrict__ aabb,
                                                     const uint32_t* __restrict__ global_id,
                                                     uint32_t* __restrict__ cross_pairs, uint64_t cap,
                                                     StepCounters* __restrict__ ctr) {
@@ -103,7 +126,6 @@ __global__ __launch_bounds__(256) void k_halo_pairs(uint32_t n_remote, uint32_t 
             if (c1[a] - c0[a] > 7) c1[a] = c0[a] + 7;  // a remote box spanning > 8 cells would alias the table
         }
     }
-    const int lane = threadIdx.x & 63;
     // wave-uniform sweep over the largest cell range in the wave
     int span[3];
     for (int a = 0; a < 3; ++a) {
@@ -120,8 +142,14 @@ __global__ __launch_bounds__(256) void k_halo_pairs(uint32_t n_remote, uint32_t 
                 uint32_t t = 0, t_end = 0;
                 if (in) {
                     const uint32_t bk = bucket_h(cx, cy, cz, axis_mask);
-                    t = bucket_start[bk];
-                    t_end = bucket_start[bk + 1];
+                    if (SLOTS) {
+                        const uint32_t have = bucket_start[bk];
+                        t = kSlots * bk;
+                        t_end = t + (have < kSlots ? have : kSlots);
+                    } else {
+                        t = bucket_start[bk];
+                        t_end = bucket_start[bk + 1];
+                    }
                 }
                 while (__any(t < t_end)) {
                     bool hit = false;
@@ -138,19 +166,24 @@ __global__ __launch_bounds__(256) void k_halo_pairs(uint32_t n_remote, uint32_t 
                         hit = same_cell && aabb_overlap(rb, bj) && global_id[j] < rgid;
                         ++t;
                     }
-                    const unsigned long long mask = __ballot(hit);
-                    if (mask) {
-                        uint32_t base = 0;
-                        if (lane == 0) base = atomicAdd(&ctr->n_cross_pairs, (uint32_t)__popcll(mask));
-                        base = (uint32_t)__shfl((int)base, 0, 64);
-                        if (hit) {
-                            const uint64_t slot = (uint64_t)base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-                            if (slot < cap) { cross_pairs[2 * slot] = j; cross_pairs[2 * slot + 1] = rgid; }
-                            else atomicOr(&ctr->overflow, 8u);
-                        }
-                    }
+                    emit_cross_pairs(hit, j, rgid, cross_pairs, cap, ctr);
                 }
             }
+    if (SLOTS) {
+        // bodies that found their bucket full are not in any slot: every record meets them directly
+        const uint32_t n_ovf = ctr->n_grid_ovf;
+        for (uint32_t o = 0; o < n_ovf; ++o) {
+            const uint32_t j = ovf[o];
+            bool hit = false;
+            if (live) {
+                aabb_t bj;
+                bj.lo = ld3(aabb, 2 * j);
+                bj.hi = ld3(aabb, 2 * j + 1);
+                hit = aabb_overlap(rb, bj) && global_id[j] < rgid;
+            }
+            emit_cross_pairs(hit, j, rgid, cross_pairs, cap, ctr);
+        }
+    }
 }
 
 static int32_t read_counters(phys_world* w) {
@@ -183,13 +216,6 @@ int32_t halo_pairs(phys_world* w, const void* dev_remote, uint64_t n_remote, uin
                    uint64_t* n_cross) {
     if (n_remote && !dev_remote) { set_error("null argument"); return PHYS_ERR_INVALID_ARG; }
     if (!w->grid_valid) { set_error("phys_halo_pairs needs the grid of an update or phys_broadphase first"); return PHYS_ERR_UNSUPPORTED; }
-    if (!w->sorted_grid_valid) {
-        // the last broad phase used the slot grid of small scenes: build the sorted one from the same AABBs now, and
-        // from now on with every broad phase (this world takes part in a halo exchange)
-        PHYS_HIP_TRY(hipMemsetAsync(w->bucket_count.p, 0, (size_t)w->grid_table_size * 4, w->stream));
-        build_sorted_grid(w);
-        w->want_sorted_grid = true;
-    }
     if (w->max_cross_pairs == 0) {
         w->max_cross_pairs = std::max<uint64_t>(4 * w->n, 4096);
         PHYS_HIP_TRY(w->cross_pairs.resize(2 * w->max_cross_pairs));
@@ -200,10 +226,16 @@ int32_t halo_pairs(phys_world* w, const void* dev_remote, uint64_t n_remote, uin
         uint32_t bits = 0;
         while ((1u << (3 * bits)) < T) ++bits;
         PHYS_PROF(w, PHYS_STAGE_MISC);
-        hipLaunchKernelGGL(k_halo_pairs, dim3((unsigned)((n_remote + 255) / 256)), dim3(256), 0, w->stream,
-                           (uint32_t)n_remote, (uint32_t)skip_first, (uint32_t)skip_count, (const HaloRecord*)dev_remote, w->bucket_start.p, T, (1u << bits) - 1u,
-                           w->sorted_ids.p, w->sorted_box.p, w->global_id.p, w->cross_pairs.p, w->max_cross_pairs,
-                           w->counters.p);
+        if (w->sorted_grid_valid)
+            hipLaunchKernelGGL(k_halo_pairs<false>, dim3((unsigned)((n_remote + 255) / 256)), dim3(256), 0, w->stream,
+                               (uint32_t)n_remote, (uint32_t)skip_first, (uint32_t)skip_count, (const HaloRecord*)dev_remote, w->bucket_start.p, T,
+                               (1u << bits) - 1u, w->sorted_ids.p, w->sorted_box.p, nullptr, w->aabb.p, w->global_id.p, w->cross_pairs.p,
+                               w->max_cross_pairs, w->counters.p);
+        else  // the slot grid of small scenes
+            hipLaunchKernelGGL(k_halo_pairs<true>, dim3((unsigned)((n_remote + 255) / 256)), dim3(256), 0, w->stream,
+                               (uint32_t)n_remote, (uint32_t)skip_first, (uint32_t)skip_count, (const HaloRecord*)dev_remote, w->bucket_count.p, T,
+                               (1u << bits) - 1u, w->slot_ids.p, w->slot_box.p, w->grid_ovf.p, w->aabb.p, w->global_id.p, w->cross_pairs.p,
+                               w->max_cross_pairs, w->counters.p);
     }
     if (!n_cross) return PHYS_OK;  // asynchronous form
     const int32_t rc = read_counters(w);

@@ -181,7 +181,6 @@ struct phys_world {
     phys::DevBuf<float> slot_box;        // the AABB next to every id slot (6 floats)
     phys::DevBuf<uint32_t> grid_ovf;     // n: bodies beyond the fourth of their bucket
     bool sorted_grid_valid = false;      // bucket_start / sorted_ids / sorted_box describe the last broad phase
-    bool want_sorted_grid = false;       // a halo exchange uses this world: always build the sorted grid
     phys::DevBuf<uint32_t> sorted_ids;   // n: body ids grouped by bucket
     phys::DevBuf<float> sorted_box;      // 6n: AABBs in bucket order (streamed by the pair kernel)
     phys::DevBuf<uint32_t> scan_block_sums;
