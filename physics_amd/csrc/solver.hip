@@ -20,6 +20,8 @@
 // Algorithmic bytes per manifold per iteration: ids, count, normal 24 + per point 40 (rA, rB,
 // masses, bias) + 12 R + 12 W (accumulated impulses), + per body 48 (v, w R+W) + 4 (inv mass) + 12 / 36
 // (inverse inertia diagonal / full).
+#include <cstdlib>
+
 #include "kernels.hpp"
 
 namespace phys {
@@ -111,6 +113,7 @@ __global__ __launch_bounds__(256) void k_rows_build(const StepCounters* __restri
                 const unsigned long long ub = used[b];
                 ticket |= ((uint32_t)__popcll(ub & below) << 16) | ((uint32_t)__popcll(ub) << 24);
             }
+            if (flow == 2 && d == 0) ticket += 1;  // fault injection (PHYS_DEBUG_FLOW_STALL): row 0 waits for a turn that never comes
         }
         rows.hdr[d] = make_uint4(a, b, (uint32_t)sm.count, ticket);
         rows.n[d] = make_float4(sm.n.x, sm.n.y, sm.n.z, 0.0f);
@@ -283,7 +286,7 @@ __device__ __forceinline__ v3 granule_v3(u32x4 g) {
     return v3_make(__uint_as_float(g.x), __uint_as_float(g.y), __uint_as_float(g.z));
 }
 
-constexpr long long kFlowTimeoutTicks = 300000000ll;  // 3 s of the 100 MHz wall clock
+constexpr long long kFlowTimeoutTicks = 300000000ll;  // 3 s of the 100 MHz wall clock (fault injection: 20 ms)
 constexpr uint64_t kFlowMaxManifolds = 400000;        // above: one launch per colour streams better
 constexpr uint64_t kFlowQuadMaxManifolds = 64000;     // below: four lanes per manifold (k_solve_flow_quad); 45k: +13 %, 108k: -32 %
 
@@ -291,7 +294,7 @@ template <bool DIAG>
 __global__ __launch_bounds__(256) void k_solve_flow(StepCounters* __restrict__ ctr, uint32_t iterations, uint32_t epoch,
                                                     RowArrays rows, float friction,
                                                     const float* __restrict__ inv_inertia, uint32_t inertia_stride,
-                                                    float* vel, float* flow_vel, uint32_t n_bodies) {
+                                                    float* vel, float* flow_vel, uint32_t n_bodies, long long timeout_ticks) {
     __shared__ uint32_t s_item;
     if (ctr->overflow) return;
     const uint32_t M = ctr->n_manifolds;
@@ -414,7 +417,7 @@ __global__ __launch_bounds__(256) void k_solve_flow(StepCounters* __restrict__ c
             else if (__any(!done && gap <= 4u)) __builtin_amdgcn_s_sleep(40);
             else __builtin_amdgcn_s_sleep(127);
             if ((++sweeps & 63u) == 0u) {
-                const bool dead = (wall_clock64() - t_start > kFlowTimeoutTicks) ||
+                const bool dead = (wall_clock64() - t_start > timeout_ticks) ||
                                   (__hip_atomic_load(&ctr->overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 16u);
                 if (dead) {  // wave-uniform: both inputs are
                     if ((threadIdx.x & 63u) == 0u) atomicOr(&ctr->overflow, 16u);
@@ -447,7 +450,7 @@ template <bool DIAG>
 __global__ __launch_bounds__(256) void k_solve_flow_quad(StepCounters* __restrict__ ctr, uint32_t iterations, uint32_t epoch,
                                                          RowArrays rows, float friction,
                                                          const float* __restrict__ inv_inertia, uint32_t inertia_stride,
-                                                         float* vel, float* flow_vel, uint32_t n_bodies) {
+                                                         float* vel, float* flow_vel, uint32_t n_bodies, long long timeout_ticks) {
     __shared__ uint32_t s_item;
     if (ctr->overflow) return;
     const uint32_t M = ctr->n_manifolds;
@@ -624,7 +627,7 @@ __global__ __launch_bounds__(256) void k_solve_flow_quad(StepCounters* __restric
             else if (__any(!done && gap <= 4u)) __builtin_amdgcn_s_sleep(40);
             else __builtin_amdgcn_s_sleep(127);
             if ((++sweeps & 63u) == 0u) {
-                const bool dead = (wall_clock64() - t_start > kFlowTimeoutTicks) ||
+                const bool dead = (wall_clock64() - t_start > timeout_ticks) ||
                                   (__hip_atomic_load(&ctr->overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 16u);
                 if (dead) {
                     if ((threadIdx.x & 63u) == 0u) atomicOr(&ctr->overflow, 16u);
@@ -674,6 +677,10 @@ void launch_solver(phys_world* w, float dt) {
     // (tickets are 16-bit: iterations x 64 colours must stay below 65536)
     const bool flow = w->flow_vel.p && h.valid && m_hint <= kFlowMaxManifolds && w->cfg.solver_iterations > 0 &&
                       w->cfg.solver_iterations < 1000;
+    // fault injection for tests/test_gpu_full_size.py: one row gets a ticket nobody will ever publish, so the bounded
+    // spin of the dataflow kernels must give up, flag the step (overflow bit 4) and let the launch end
+    static const bool stall = getenv("PHYS_DEBUG_FLOW_STALL") != nullptr;
+    const long long timeout_ticks = stall ? 2000000ll : kFlowTimeoutTicks;
     ColorTableJob table{};
     if (w->ctab_job_pending) {
         const uint32_t tab = w->ctab_job_tab, other = tab ^ 1u;
@@ -688,7 +695,7 @@ void launch_solver(phys_world* w, float dt) {
     }
     { PHYS_PROF(w, PHYS_STAGE_ROWS); hipLaunchKernelGGL(k_rows_build, grid_for_count(m_hint), tb, 0, s, w->counters.p, rows, sp, w->row_src.p, w->man_a.p, w->man_b.p, w->man_count.p,
                        w->man_normal.p, w->man_points.p, w->pos.p, w->vel.p, w->inv_inertia.p, w->man_color.p,
-                       w->color_state.p, flow ? 1 : 0, table); }
+                       w->color_state.p, flow ? (stall ? 2 : 1) : 0, table); }
     if (flow) {
         if (++w->flow_epoch > 0xFFFFu) {  // tags would repeat: forget every old one
             (void)hipMemsetAsync(w->flow_vel.p, 0, 8 * w->n * sizeof(float), s);
@@ -704,7 +711,7 @@ void launch_solver(phys_world* w, float dt) {
         if (items > most) items = most;  // the remaining items are taken by the same workgroups
         PHYS_PROF(w, PHYS_STAGE_SOLVE_FLOW);
 #define PHYS_FLOW_LAUNCH(K, D) hipLaunchKernelGGL((K<D>), dim3((unsigned)items), dim3(threads), 0, s, w->counters.p, w->cfg.solver_iterations, \
-                               w->flow_epoch, rows, sp.friction, inertia, stride, w->vel.p, w->flow_vel.p, (uint32_t)w->n)
+                               w->flow_epoch, rows, sp.friction, inertia, stride, w->vel.p, w->flow_vel.p, (uint32_t)w->n, timeout_ticks)
         if (quad) { if (diag) PHYS_FLOW_LAUNCH(k_solve_flow_quad, true); else PHYS_FLOW_LAUNCH(k_solve_flow_quad, false); }
         else { if (diag) PHYS_FLOW_LAUNCH(k_solve_flow, true); else PHYS_FLOW_LAUNCH(k_solve_flow, false); }
 #undef PHYS_FLOW_LAUNCH

@@ -170,3 +170,28 @@ def test_stats_and_stage_profile_are_consistent():
     counts = w.get_color_counts()
     st = w.get_stats()
     assert counts.sum() == st.n_manifolds and (counts[:st.n_colors] > 0).all()
+
+
+def test_dataflow_solver_gives_up_instead_of_hanging():
+    """Every spin of the dataflow kernels is bounded. With PHYS_DEBUG_FLOW_STALL one row is handed a ticket that is
+    never published (its body's chain can never advance): the launch must still END, flag the step, and phys_sync
+    must report PHYS_ERR_HIP - never a hung GPU. Runs in a child process (the switch is read once per process)."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import sys; sys.path.insert(0, '.')\n"
+        "import physics_amd\n"
+        "from physics_amd import scenes\n"
+        "sc = scenes.c1()\n"
+        "w = physics_amd.World(sc.config()); sc.populate(w)\n"
+        "try:\n"
+        "    w.update_n(16666667, 120); w.sync()\n"
+        "    print('NO ERROR', w.get_stats().overflow)\n"
+        "except physics_amd.PhysError as e:\n"
+        "    print('ERROR', e.code, w.get_stats().overflow & 16)\n"
+    )
+    env = dict(os.environ, PHYS_DEBUG_FLOW_STALL="1")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=180)
+    assert "ERROR -3 16" in out.stdout, out.stdout + out.stderr
