@@ -28,9 +28,12 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s achievable
 
 KERNEL_OF_STAGE = {
-    "step_full": "k_step_full", "velocity_aabb": "k_step_velocity_aabb", "grid": "k_cell_assign+scan+k_scatter",
-    "pairs": "k_find_pairs", "narrow": "k_narrowphase", "color": "k_color_round",
-    "rows": "k_rows_build+k_color_hist+k_color_offsets+k_color_place", "solve": "k_solve_color",
+    "step_full": "k_step_full", "velocity_aabb": "k_step_velocity_aabb",
+    "grid": "k_cell_insert",  # small scenes; larger ones: k_cell_assign + scan + k_scatter
+    "pairs": "k_find_pairs", "narrow": "k_narrowphase",
+    "color": "k_color_small",  # small scenes; larger ones: k_color_round x rounds + k_color_finish
+    "rows": "k_rows_build",    # + k_color_hist / k_color_offsets / k_color_place beyond 24k manifolds
+    "solve": "k_solve_color",
     "solve_tail": "k_solve_tail", "solve_flow": "k_solve_flow", "position": "k_step_position",
 }
 
