@@ -394,7 +394,7 @@ __global__ __launch_bounds__(kPairThreads) void k_find_pairs(const uint32_t* __r
 // pair kernel reads the neighbours' slots directly. A body that finds the eight slots taken goes to a short overflow list that every body also tests against, so the pair SET is the same as with the
 // sorted grid whatever the occupancy; only the speed depends on it.
 constexpr uint32_t kSlotsPerBucket = 8;
-constexpr uint32_t kSlotGridMaxBodies = 16384;
+constexpr uint32_t kSlotGridMaxBodies = 32768;  // beyond, streaming the sorted boxes is as fast
 
 __global__ __launch_bounds__(256) void k_cell_insert(uint32_t n, const float* __restrict__ aabb,
                                                      const uint32_t* __restrict__ shape, StepCounters* __restrict__ ctr,
