@@ -320,7 +320,8 @@ int32_t phys_step(phys_world* w, uint64_t dt_nanos) {
 
 // one PhysicsState::update (physics.rs:41-55), enqueued without synchronising
 static int32_t enqueue_update(phys_world* w, float dt) {
-    const bool collisions = (w->cfg.flags & PHYS_FLAG_COLLISIONS) != 0;
+    // a zero-length step has no contact problem to solve (the bias terms divide by dt): plain RigidBody::step then
+    const bool collisions = (w->cfg.flags & PHYS_FLAG_COLLISIONS) != 0 && dt > 0.0f;
     if (collisions) poll_snapshots(w);
     const bool have_constraints = !w->constraints.empty();
     bool gravity_pending = true;

@@ -195,3 +195,19 @@ def test_dataflow_solver_gives_up_instead_of_hanging():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=180)
     assert "ERROR -3 16" in out.stdout, out.stdout + out.stderr
+
+
+def test_zero_length_step_is_harmless():
+    """dt = 0 with collisions on: the contact bias divides by dt, so such a step is taken as a plain RigidBody::step
+    (which moves nothing): no NaN, poses unchanged."""
+    import physics_amd
+    from physics_amd import scenes
+    sc = scenes.c1()
+    w = physics_amd.World(sc.config())
+    sc.populate(w)
+    w.update_n(DT, 90)
+    before = w.get_transforms()
+    w.update(0)
+    w.sync()
+    after = w.get_transforms()
+    assert np.isfinite(after[0]).all() and np.array_equal(before[0], after[0]) and np.array_equal(before[1], after[1])
