@@ -119,7 +119,8 @@ int32_t oracle_step(oracle_world* w, uint64_t dt_nanos) {
 int32_t oracle_update(oracle_world* w, uint64_t dt_nanos) {
     PhysicsState& s = w->state;
     if (s.entities.empty()) return fail(PHYS_ERR_NO_BODIES, "update with no bodies");
-    if (!(w->cfg.flags & PHYS_FLAG_COLLISIONS)) {
+    // (a zero-length step has no contact problem to solve - the bias terms divide by dt - and is a plain update)
+    if (!(w->cfg.flags & PHYS_FLAG_COLLISIONS) || !(duration_as_secs_f32(dt_nanos) > 0.0f)) {
         if (!s.update(dt_nanos)) return fail(PHYS_ERR_SINGULAR_INERTIA, "singular inertia tensor");
     } else {
         // collision mode: physics.rs:41-55 with the contact stages between the velocity and the
