@@ -3,7 +3,8 @@
 
 A "step" is one PhysicsState::update over one synthetic scene resident in HBM (SURVEY.md §8 row D).
 N = 1 workload: BASELINE.json configs[1] = C2, 10 000 falling cubes + ground contacts, f32. The scene is
-pre-rolled (untimed, part of set-up) until the pile is in contact, so the timed steps carry contacts.
+pre-rolled (untimed, part of set-up) until the pile is in contact, so the timed steps carry contacts; by default
+1000 steps are timed, during which the pile collapses and the contact count doubles.
 N > 1: weak scaling; every rank owns one C2-shaped slab placed side by side along x, the broad phase
 exchanges boundary AABBs with one RCCL all-gather per step, narrow phase + solver stay on owned bodies.
 
@@ -209,19 +210,22 @@ def cpu_baseline(scene, preroll, sample_steps):
     return {"value": round(scene.n * sample_steps / dt, 1), "unit": "body-steps/s", "cores": 1, "kind": "port",
             "steps_per_sec": round(sample_steps / dt, 3),
             "sample": f"oracle (scalar C++ restatement + CPU collision stages, 1 thread; the Rust reference is not "
-                      f"buildable here), same scene, steps {preroll}..{preroll + sample_steps} of the same trajectory"}
+                      f"buildable here), same scene, steps {preroll}..{preroll + sample_steps} of the same trajectory (a "
+                      f"bounded sample: the first steps of the timed window; later steps carry more contacts)"}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=-1, help="timed steps (default: 1000 for c1 / c2, 200 otherwise: SURVEY.md §8 D)")
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="c2", choices=["c1", "c2", "c3", "c5", "t1m", "c4"])
     ap.add_argument("--preroll", type=int, default=-1, help="untimed set-up steps (default per workload)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the 1M-body target run appended at N=1")
     args = ap.parse_args()
+    if args.steps < 0:
+        args.steps = 1000 if args.workload in ("c1", "c2") else 200
 
     import torch
     import physics_amd

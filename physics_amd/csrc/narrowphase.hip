@@ -404,12 +404,12 @@ __global__ __launch_bounds__(1024) void k_color_place(uint64_t max_manifolds, co
     }
 }
 
-// Small scenes (<= 24k manifolds): the WHOLE colouring stage in ONE launch of ONE workgroup - every
+// Small scenes (<= 40k manifolds): the WHOLE colouring stage in ONE launch of ONE workgroup - every
 // Jones-Plassmann round (over a list of the uncoloured manifolds gathered into LDS: with persistent colouring
 // only the new ones), the colour-major counting sort, and the snapshot of the counters into pinned host memory
 // (the launch-size hints of later steps) - instead of ~3 round launches + finish + sort + a copy.
 constexpr int kSmallList = 6144;  // ids per list; two lists: the uncoloured of this round / of the next
-constexpr int kSmallTrips = 24;  // manifolds per thread kept in registers: 24 x 1024 = the `small` limit of launch_coloring
+constexpr int kSmallTrips = 40;  // manifolds per thread kept in registers: 40 x 1024 = the `small` limit of launch_coloring
 __global__ __launch_bounds__(kColorThreads) void k_color_small(uint64_t max_manifolds, const uint32_t* __restrict__ man_a,
                                                               const uint32_t* __restrict__ man_b, uint32_t* man_color,
                                                               const uint64_t* __restrict__ man_prio,
@@ -617,7 +617,7 @@ void launch_coloring(phys_world* w) {
     const bool full = ((w->color_epoch % PHYS_COLOR_CACHE_PERIOD) == 0) || !w->ctab_valid;
     w->snap_tag_full = full;
     const bool known = w->hint.valid && (!full || w->hint.full_rounds > 0);
-    const bool small = w->hint.valid && w->hint.n_manifolds <= 24576u;
+    const bool small = w->hint.valid && w->hint.n_manifolds <= (uint32_t)(kSmallTrips * kColorThreads);
     bool snapshot_done = false;
     if (small) {
         // one workgroup does the whole stage, snapshot of the counters included

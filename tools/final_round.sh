@@ -11,7 +11,7 @@ echo "bench done"
 PHYS_BENCH_REHEARSAL=1 timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29541 bench.py --gpus 2 --steps 100 > gpurun_out/bench_n2_rehearsal.log 2>&1 && tail -c 400 gpurun_out/bench_n2_rehearsal.log | head -c 200; echo
 PHYS_BENCH_FORCE_DIST=1 MASTER_ADDR=127.0.0.1 timeout -k 10 300 python bench.py --steps 100 > gpurun_out/bench_dist1.log 2>&1 && echo "one-rank RCCL ok"
 for wl in c1 c3 c4 c5; do
-  timeout -k 10 400 python bench.py --workload $wl --no-cpu-baseline --no-extra --steps 200 > gpurun_out/fin_$wl.log 2>&1
+  timeout -k 10 400 python bench.py --workload $wl --no-cpu-baseline --no-extra > gpurun_out/fin_$wl.log 2>&1
   python - <<PY
 import json
 d=json.loads(open("gpurun_out/fin_$wl.log").read().strip().splitlines()[-1])

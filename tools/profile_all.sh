@@ -5,8 +5,8 @@
 set -e
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 for wl in c2 t1m; do
-  steps=200; [ "$wl" = "t1m" ] && steps=60
-  args="--workload $wl --steps $steps --no-cpu-baseline --no-extra"
+  # the same commands bench.py runs by default: C2 with its default 1000 timed steps, the 1M scene with 60
+  args="--workload $wl --no-cpu-baseline --no-extra"; [ "$wl" = "t1m" ] && args="$args --steps 60"
   timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$wl -- python3 bench.py $args > gpurun_out/prof_$wl.log 2>&1
   echo "trace $wl done"
   for c in FETCH_SIZE WRITE_SIZE; do
