@@ -54,7 +54,19 @@ PHYS_HD geom_t geom_make(v3 c, quat q, v3 h, uint32_t type) {
     return g;
 }
 
-PHYS_HD v3 m33_col(const m33* R, int c) { return v3_make(R->m[c], R->m[3 + c], R->m[6 + c]); }
+/* column c of a row-major 3x3. Selections, not indexing: a matrix (or any small array) indexed by a run-time value
+ * is put into per-lane scratch memory by the GPU compiler, and nothing of this header may live there (DESIGN.md:
+ * kernels that used scratch lost data whenever a scratch-using kernel of another stream ran beside them). */
+PHYS_HD v3 m33_col(const m33* R, int c) {
+    const float m0 = R->m[0], m1 = R->m[1], m2 = R->m[2], m3 = R->m[3], m4 = R->m[4], m5 = R->m[5], m6 = R->m[6],
+                m7 = R->m[7], m8 = R->m[8]; /* all nine read first: the selections below are between values */
+    return v3_make(c == 0 ? m0 : (c == 1 ? m1 : m2), c == 0 ? m3 : (c == 1 ? m4 : m5),
+                   c == 0 ? m6 : (c == 1 ? m7 : m8));
+}
+PHYS_HD float sel3(const float* a, int i) {
+    const float a0 = a[0], a1 = a[1], a2 = a[2];
+    return i == 0 ? a0 : (i == 1 ? a1 : a2);
+}
 /* R^T * v (world -> local for an orthonormal R) */
 PHYS_HD v3 m33_tmul_v3(const m33* R, v3 v) {
     return v3_make((R->m[0] * v.x + R->m[3] * v.y) + R->m[6] * v.z,
@@ -95,6 +107,7 @@ PHYS_HD int aabb_overlap(aabb_t a, aabb_t b) {
 PHYS_HD void manifold_clear(manifold_t* m) {
     m->count = 0;
     m->normal = v3_make(0.0f, 1.0f, 0.0f);
+    PHYS_UNROLL
     for (int k = 0; k < 4; ++k) { m->pt[k] = v3_make(0.0f, 0.0f, 0.0f); m->depth[k] = 0.0f; }
 }
 
@@ -174,6 +187,7 @@ PHYS_HD int clip_poly(const v3* in, int n_in, v3 c, v3 u, float lim, v3* out) {
 PHYS_HD void manifold_reduce(const v3* p, const float* depth, int n, v3 normal, manifold_t* m) {
     if (n <= 4) {
         m->count = n;
+        PHYS_UNROLL
         for (int k = 0; k < 4; ++k) if (k < n) { m->pt[k] = p[k]; m->depth[k] = depth[k]; }
         return;
     }
@@ -192,12 +206,15 @@ PHYS_HD void manifold_reduce(const v3* p, const float* depth, int n, v3 normal, 
         if (area > amax) { amax = area; i2 = k; }
         if (area < amin) { amin = area; i3 = k; }
     }
-    int c = 0;
-    m->pt[c] = p[i0]; m->depth[c] = depth[i0]; ++c;
-    m->pt[c] = p[i1]; m->depth[c] = depth[i1]; ++c;
-    if (i2 >= 0) { m->pt[c] = p[i2]; m->depth[c] = depth[i2]; ++c; }
-    if (i3 >= 0) { m->pt[c] = p[i3]; m->depth[c] = depth[i3]; ++c; }
-    m->count = c;
+    m->pt[0] = p[i0]; m->depth[0] = depth[i0];
+    m->pt[1] = p[i1]; m->depth[1] = depth[i1];
+    /* the area extremes follow in that order; each manifold slot is written at a fixed index (no run-time
+     * indexing of the manifold: it stays in registers on the GPU) */
+    const int has2 = i2 >= 0, has3 = i3 >= 0;
+    const int s2 = has2 ? i2 : i3;
+    if (has2 || has3) { m->pt[2] = p[s2]; m->depth[2] = depth[s2]; }
+    if (has2 && has3) { m->pt[3] = p[i3]; m->depth[3] = depth[i3]; }
+    m->count = 2 + has2 + has3;
 }
 
 /* face contact: Ref's face (axis r, side sgn) against the most anti-parallel face of Inc.
@@ -247,18 +264,22 @@ PHYS_HD void collide_box_box(const geom_t* A, const geom_t* B, float margin, man
     float C[3][3], absC[3][3], tA[3], tB[3], hA[3], hB[3];
     hA[0] = A->h.x; hA[1] = A->h.y; hA[2] = A->h.z;
     hB[0] = B->h.x; hB[1] = B->h.y; hB[2] = B->h.z;
+    PHYS_UNROLL
     for (int i = 0; i < 3; ++i) {
         const v3 ai = m33_col(&A->R, i);
         tA[i] = v3_dot(d, ai);
+        PHYS_UNROLL
         for (int j = 0; j < 3; ++j) {
             C[i][j] = v3_dot(ai, m33_col(&B->R, j));
             absC[i][j] = det_absf(C[i][j]) + 1.0e-6f;
         }
     }
+    PHYS_UNROLL
     for (int j = 0; j < 3; ++j) tB[j] = v3_dot(d, m33_col(&B->R, j));
 
     /* face axes of A */
     float aMax = -3.0e38f; int aAxis = 0;
+    PHYS_UNROLL
     for (int i = 0; i < 3; ++i) {
         const float s = det_absf(tA[i]) - (hA[i] + ((absC[i][0] * hB[0] + absC[i][1] * hB[1]) + absC[i][2] * hB[2]));
         if (s > margin) return;
@@ -266,6 +287,7 @@ PHYS_HD void collide_box_box(const geom_t* A, const geom_t* B, float margin, man
     }
     /* face axes of B */
     float bMax = -3.0e38f; int bAxis = 0;
+    PHYS_UNROLL
     for (int j = 0; j < 3; ++j) {
         const float s = det_absf(tB[j]) - (hB[j] + ((absC[0][j] * hA[0] + absC[1][j] * hA[1]) + absC[2][j] * hA[2]));
         if (s > margin) return;
@@ -273,8 +295,10 @@ PHYS_HD void collide_box_box(const geom_t* A, const geom_t* B, float margin, man
     }
     /* edge axes a_i x b_j */
     float eMax = -3.0e38f; int eI = -1, eJ = -1;
+    PHYS_UNROLL
     for (int i = 0; i < 3; ++i) {
         const int i1 = (i + 1) % 3, i2 = (i + 2) % 3;
+        PHYS_UNROLL
         for (int j = 0; j < 3; ++j) {
             const int j1 = (j + 1) % 3, j2 = (j + 2) % 3;
             const float len2 = 1.0f - C[i][j] * C[i][j];
@@ -299,6 +323,7 @@ PHYS_HD void collide_box_box(const geom_t* A, const geom_t* B, float margin, man
         if (v3_dot(n, d) < 0.0f) n = v3_neg(n);
         /* supporting edges */
         v3 pA = A->c, pB = B->c;
+        PHYS_UNROLL
         for (int k = 0; k < 3; ++k) {
             if (k != eI) {
                 const v3 ak = m33_col(&A->R, k);
@@ -313,7 +338,7 @@ PHYS_HD void collide_box_box(const geom_t* A, const geom_t* B, float margin, man
         }
         /* closest points of the two lines pA + s*ai, pB + t*bj */
         const v3 w = v3_sub(pA, pB);
-        const float b = C[eI][eJ];
+        const float b = v3_dot(ai, bj); /* == C[eI][eJ], recomputed so that C is never indexed at run time */
         const float dd = v3_dot(ai, w), ee = v3_dot(bj, w);
         const float den = 1.0f - b * b;
         const float sa = (b * ee - dd) / den;
@@ -328,12 +353,12 @@ PHYS_HD void collide_box_box(const geom_t* A, const geom_t* B, float margin, man
     }
     if (kRel * bMax > aMax + kAbs) {
         /* reference = B; its face looks back toward A */
-        const float sgn = tB[bAxis] > 0.0f ? -1.0f : 1.0f;
+        const float sgn = sel3(tB, bAxis) > 0.0f ? -1.0f : 1.0f;
         const v3 nref = v3_scale(m33_col(&B->R, bAxis), sgn); /* B -> A */
         m->normal = v3_neg(nref);
         box_face_contact(B, A, bAxis, sgn, margin, m->normal, m, ws);
     } else {
-        const float sgn = tA[aAxis] < 0.0f ? -1.0f : 1.0f;
+        const float sgn = sel3(tA, aAxis) < 0.0f ? -1.0f : 1.0f;
         m->normal = v3_scale(m33_col(&A->R, aAxis), sgn); /* A -> B */
         box_face_contact(A, B, aAxis, sgn, margin, m->normal, m, ws);
     }

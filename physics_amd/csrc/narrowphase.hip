@@ -46,6 +46,8 @@ __global__ __launch_bounds__(kNpThreads) void k_narrowphase(
     constexpr int kWsStride = sizeof(clip_ws_t) / 4 + 1;
     __shared__ float ws_lds[kNpThreads * kWsStride];
     clip_ws_t* ws = reinterpret_cast<clip_ws_t*>(ws_lds + threadIdx.x * kWsStride);
+    // nothing else of a lane is indexed at run time: the shapes and the manifold stay in registers, and the kernel
+    // uses no scratch memory at all (a rule of this library - tests/test_build_rules.py)
     const uint32_t np_raw = ctr->n_pairs;
     const uint32_t n_pairs = (uint64_t)np_raw < max_pairs ? np_raw : (uint32_t)max_pairs;
     const uint32_t total = n_ground + n_pairs;

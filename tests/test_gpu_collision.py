@@ -331,3 +331,37 @@ def test_one_lane_dataflow_kernel_with_full_inertia_tensors():
     w.profile_enable(True)
     w.update_n(DT, 2)
     assert "solve_flow" in w.profile_get()[0]
+
+
+@pytest.mark.xfail(strict=False, reason="open issue, DESIGN.md section 7: ulp-level divergence while hipBLASLt bf16 GEMM waves share the CUs")
+def test_every_step_under_a_concurrent_gemm():
+    """A bf16 GEMM is launched on another stream right before every step of one world; a second world steps
+    quietly. Both are synchronised after every step (the way a frame loop uses the library) and should stay
+    bit-identical. They do not always: in about half of the runs some step's narrow phase sees a body's transform
+    of the step before (a few ulp off on resting bodies), and the worlds part from there. Alone on the GPU, or next to
+    copies, element-wise kernels, reductions or an fp32 GEMM, the same loop is bit-stable for 10^5 steps. The
+    evidence, what was ruled out and the diagnostic tools (tools/race_probe.py, tools/soak_matrix.sh) are in
+    DESIGN.md section 7; this test is the compact form of the probe and is expected to fail until that is closed."""
+    import torch
+    import physics_amd
+    from physics_amd import scenes
+    sc = scenes.c2()
+    busy, quiet = physics_amd.World(sc.config()), physics_amd.World(sc.config())
+    for w in (busy, quiet):
+        sc.populate(w)
+    side = torch.cuda.Stream()
+    m = torch.randn(2048, 2048, device="cuda", dtype=torch.bfloat16)
+    for step in range(1, 301):
+        with torch.cuda.stream(side):
+            m2 = m @ m
+            m3 = m2 @ m
+        busy.update(DT)
+        busy.sync()
+        torch.cuda.synchronize()
+        quiet.update(DT)
+        quiet.sync()
+        if step % 10 == 0 or step > 30:
+            sa, sb = busy.get_stats(), quiet.get_stats()
+            assert (sa.n_pairs, sa.n_manifolds, sa.n_contacts) == (sb.n_pairs, sb.n_manifolds, sb.n_contacts), f"step {step}"
+    for x, y in zip(busy.get_transforms() + busy.get_velocities(), quiet.get_transforms() + quiet.get_velocities()):
+        assert np.array_equal(x, y)
