@@ -31,6 +31,18 @@ def test_no_kernel_uses_scratch_memory(kernel_table):
     assert not offenders, f"kernels with scratch memory or register spills: {offenders}"
 
 
+def test_no_packed_fp32_arithmetic():
+    """Rule: no v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32 anywhere (csrc/Makefile: -packed-fp32-ops). Next to the MFMA
+    waves of another stream's bf16 GEMM these returned, for 16 lanes at a time, results off in the 5th digit - the
+    narrow phase's clip planes moved by 1e-4 (tools/frozen_probe.py)."""
+    import code_objects
+    if not os.path.exists(LIB):
+        import __graft_entry__
+        __graft_entry__.build()
+    found = code_objects.count_instructions(LIB, ("v_pk_mul_f32", "v_pk_add_f32", "v_pk_fma_f32"))
+    assert found == 0, f"{found} packed fp32 arithmetic instructions in libphysics_hip.so"
+
+
 def test_lds_fits_one_workgroup(kernel_table):
     # 160 KB of LDS per CU on gfx950; a static allocation above 64 KB needs the whole-CU budget and must stay under it
     for k in kernel_table:

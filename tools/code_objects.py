@@ -56,6 +56,18 @@ def kernels(lib):
     return out
 
 
+def count_instructions(lib, mnemonics):
+    """Occurrences of the given mnemonics in the disassembly of every code object of the library."""
+    total = 0
+    for image in code_objects(lib):
+        with tempfile.NamedTemporaryFile(suffix=".elf") as f:
+            f.write(image)
+            f.flush()
+            text = subprocess.run([f"{LLVM}/llvm-objdump", "-d", f.name], check=True, capture_output=True, text=True).stdout
+        total += sum(text.count(m) for m in mnemonics)
+    return total
+
+
 if __name__ == "__main__":
     here = os.path.dirname(os.path.abspath(__file__))
     lib = sys.argv[1] if len(sys.argv) > 1 else os.path.join(here, "..", "physics_amd", "csrc", "libphysics_hip.so")
@@ -63,4 +75,4 @@ if __name__ == "__main__":
     for k in sorted(ks, key=lambda k: k["name"]):
         short = subprocess.run(["c++filt", k["name"]], capture_output=True, text=True).stdout.split("(")[0].strip()
         print(f"{short[:60]:60s} scratch {k['scratch']:4d}  lds {k['lds']:7d}  vgprs {k['vgprs']:4d}  sgprs {k['sgprs']:4d}  spills {k['spills']}")
-    print(f"{len(ks)} kernels")
+    print(f"{len(ks)} kernels; packed fp32 arithmetic instructions:", count_instructions(lib, ("v_pk_mul_f32", "v_pk_add_f32", "v_pk_fma_f32")))
