@@ -2,7 +2,7 @@
 roots, per-lane LDS slices - the shape of the narrow phase) is launched repeatedly, alone and with a bf16 GEMM on a
 second stream, and every output is compared bit for bit with the first quiet launch.
 
-    python tools/alu_probe.py [launches] [blocks] [iters] [gemms per launch]
+    python tools/alu_probe.py [launches] [blocks] [iters] [gemms per launch] [packed]
 """
 import ctypes
 import os
@@ -20,10 +20,12 @@ if len(sys.argv) > 1 and sys.argv[1] == "build":
     sys.exit(0)
 lib = ctypes.CDLL(lib_path)
 lib.alu_probe_launch.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+lib.alu_probe_launch_pk.argtypes = lib.alu_probe_launch.argtypes
 launches = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
 blocks = int(sys.argv[2]) if len(sys.argv) > 2 else 512
 iters = int(sys.argv[3]) if len(sys.argv) > 3 else 400
 gemms = int(sys.argv[4]) if len(sys.argv) > 4 else 2
+entry = lib.alu_probe_launch_pk if (len(sys.argv) > 5 and sys.argv[5] == "packed") else lib.alu_probe_launch
 n = blocks * 128
 torch.manual_seed(1)
 seed = torch.rand(n, device="cuda") * 4 + 1
@@ -38,7 +40,7 @@ def launch(load):
             x = m
             for _ in range(gemms):
                 x = x @ m
-    rc = lib.alu_probe_launch(out.data_ptr(), seed.data_ptr(), blocks, iters, mine.cuda_stream)
+    rc = entry(out.data_ptr(), seed.data_ptr(), blocks, iters, mine.cuda_stream)
     assert rc == 0, rc
     torch.cuda.synchronize()
     return out
