@@ -10,7 +10,7 @@ from physics_amd import scenes
 DT = 16_666_667
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 400
 flags_extra = physics_amd.FLAG_SOLVER_PER_COLOR if (len(sys.argv) > 2 and sys.argv[2] == "percolour") else 0
-sc = scenes.c2()
+sc = getattr(scenes, sys.argv[3] if len(sys.argv) > 3 else "c2")()
 A = physics_amd.World(sc.config(flags=sc.flags | flags_extra))
 B = physics_amd.World(sc.config(flags=sc.flags | flags_extra))
 for w in (A, B):
