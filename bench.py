@@ -200,18 +200,33 @@ def copy_ceiling_gbs(device):
 def cpu_baseline(scene, preroll, sample_steps):
     from oracle import binding as ob
     from physics_amd.scenes import DT_NANOS
-    o = ob.OracleWorld(scene.config(), trig=ob.TRIG_DET)
-    scene.populate(o)
-    o.update_n(DT_NANOS, preroll)
-    t0 = time.perf_counter()
-    o.update_n(DT_NANOS, sample_steps)
-    dt = time.perf_counter() - t0
-    o.close()
+
+    def timed(threads):
+        o = ob.OracleWorld(scene.config(), trig=ob.TRIG_DET)
+        scene.populate(o)
+        o.set_threads(threads)
+        o.update_n(DT_NANOS, preroll)
+        t0 = time.perf_counter()
+        o.update_n(DT_NANOS, sample_steps)
+        dt = time.perf_counter() - t0
+        o.close()
+        return dt
+
+    dt = timed(1)
+    # additionally the OpenMP variant of the same oracle (same bits for any thread count) on the host
+    # cores this process may use, at most 16 (the CPU share of one GPU on the bench boxes)
+    cores = min(len(os.sched_getaffinity(0)), 16)
+    dt_mt = timed(cores) if cores > 1 else dt
     return {"value": round(scene.n * sample_steps / dt, 1), "unit": "body-steps/s", "cores": 1, "kind": "port",
             "steps_per_sec": round(sample_steps / dt, 3),
             "sample": f"oracle (scalar C++ restatement + CPU collision stages, 1 thread; the Rust reference is not "
                       f"buildable here), same scene, steps {preroll}..{preroll + sample_steps} of the same trajectory (a "
-                      f"bounded sample: the first steps of the timed window; later steps carry more contacts)"}
+                      f"bounded sample: the first steps of the timed window; later steps carry more contacts)",
+            "openmp": {"value": round(scene.n * sample_steps / dt_mt, 1), "unit": "body-steps/s", "cores": cores,
+                       "steps_per_sec": round(sample_steps / dt_mt, 3),
+                       "note": "same oracle, same sample, OpenMP over the independent loops of the collision stages "
+                               "(AABBs, grid search, narrow phase, row preparation, the manifolds of one colour); the "
+                               "reference itself is single-threaded"}}
 
 
 def main():

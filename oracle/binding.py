@@ -43,6 +43,7 @@ def load():
         "oracle_apply_gravity": (C.c_int32, [vp]),
         "oracle_step": (C.c_int32, [vp, C.c_uint64]),
         "oracle_update": (C.c_int32, [vp, C.c_uint64]),
+        "oracle_set_threads": (C.c_int32, [vp, C.c_int32]),
         "oracle_get_transforms": (C.c_int32, [vp, f32p, f32p]),
         "oracle_get_velocities": (C.c_int32, [vp, f32p, f32p]),
         "oracle_get_forces": (C.c_int32, [vp, f32p, f32p]),
@@ -151,6 +152,10 @@ class OracleWorld:
 
     def step(self, dt_nanos):
         self._ck(self.lib.oracle_step(self.h, dt_nanos))
+
+    def set_threads(self, threads):
+        """OpenMP variant of the collision stages (same results for any thread count)."""
+        self._ck(self.lib.oracle_set_threads(self.h, int(threads)))
 
     def update(self, dt_nanos):
         self._ck(self.lib.oracle_update(self.h, dt_nanos))

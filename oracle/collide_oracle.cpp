@@ -1,6 +1,8 @@
 // collide_oracle.cpp — CPU ORACLE (test infrastructure, NOT product code). See collide_oracle.hpp.
 #include "collide_oracle.hpp"
 
+#include <omp.h>
+
 #include <algorithm>
 #include <cmath>
 #include <numeric>
@@ -25,7 +27,9 @@ static inline quat Q(const float* p) { quat q; q.i = p[0]; q.j = p[1]; q.k = p[2
 void CollisionWorld::compute_aabbs(const std::vector<RigidBody>& bodies) {
     const size_t n = bodies.size();
     aabb.resize(6 * n);
-    for (size_t i = 0; i < n; ++i) {
+#pragma omp parallel for schedule(static) num_threads(threads) if (threads > 1)
+    for (long long ii = 0; ii < (long long)n; ++ii) {
+        const size_t i = (size_t)ii;
         const aabb_t b = body_aabb(V(bodies[i].position), Q(bodies[i].rotation), V(&half_extent[3 * i]), shape_type[i], margin);
         aabb[6 * i + 0] = b.lo.x; aabb[6 * i + 1] = b.lo.y; aabb[6 * i + 2] = b.lo.z;
         aabb[6 * i + 3] = b.hi.x; aabb[6 * i + 4] = b.hi.y; aabb[6 * i + 5] = b.hi.z;
@@ -87,20 +91,29 @@ void CollisionWorld::broadphase_grid() {
     keyed.reserve(ids.size());
     for (uint32_t i : ids) keyed.emplace_back(key_of(cell_of(i, 0), cell_of(i, 1), cell_of(i, 2)), i);
     std::sort(keyed.begin(), keyed.end());
-    for (uint32_t i : ids) {
-        const int64_t cx = cell_of(i, 0), cy = cell_of(i, 1), cz = cell_of(i, 2);
-        const aabb_t bi = box_at(aabb, i);
-        for (int64_t dx = -1; dx <= 1; ++dx)
-            for (int64_t dy = -1; dy <= 1; ++dy)
-                for (int64_t dz = -1; dz <= 1; ++dz) {
-                    const uint64_t key = key_of(cx + dx, cy + dy, cz + dz);
-                    auto it = std::lower_bound(keyed.begin(), keyed.end(), std::make_pair(key, (uint32_t)0));
-                    for (; it != keyed.end() && it->first == key; ++it) {
-                        const uint32_t j = it->second;
-                        if (j > i && aabb_overlap(bi, box_at(aabb, j))) pairs.emplace_back(i, j);
+    // neighbour search per body is independent; the final sort fixes the order whatever the thread count
+    std::vector<std::vector<std::pair<uint32_t, uint32_t>>> found((size_t)(threads > 1 ? threads : 1));
+#pragma omp parallel num_threads(threads) if (threads > 1)
+    {
+        std::vector<std::pair<uint32_t, uint32_t>>& out = found[(size_t)omp_get_thread_num()];
+#pragma omp for schedule(static)
+        for (long long q = 0; q < (long long)ids.size(); ++q) {
+            const uint32_t i = ids[(size_t)q];
+            const int64_t cx = cell_of(i, 0), cy = cell_of(i, 1), cz = cell_of(i, 2);
+            const aabb_t bi = box_at(aabb, i);
+            for (int64_t dx = -1; dx <= 1; ++dx)
+                for (int64_t dy = -1; dy <= 1; ++dy)
+                    for (int64_t dz = -1; dz <= 1; ++dz) {
+                        const uint64_t key = key_of(cx + dx, cy + dy, cz + dz);
+                        auto it = std::lower_bound(keyed.begin(), keyed.end(), std::make_pair(key, (uint32_t)0));
+                        for (; it != keyed.end() && it->first == key; ++it) {
+                            const uint32_t j = it->second;
+                            if (j > i && aabb_overlap(bi, box_at(aabb, j))) out.emplace_back(i, j);
+                        }
                     }
-                }
+        }
     }
+    for (const auto& part : found) pairs.insert(pairs.end(), part.begin(), part.end());
     std::sort(pairs.begin(), pairs.end());
 }
 
@@ -111,32 +124,36 @@ static inline geom_t geom_of(const RigidBody& b, const float* h, uint32_t type) 
 void CollisionWorld::narrowphase(const std::vector<RigidBody>& bodies) {
     manifolds.clear();
     n_contacts = 0;
-    for (const auto& pr : pairs) {
-        const uint32_t a = pr.first, b = pr.second;
-        const geom_t ga = geom_of(bodies[a], &half_extent[3 * a], shape_type[a]);
-        const geom_t gb = geom_of(bodies[b], &half_extent[3 * b], shape_type[b]);
-        manifold_t m;
+    // every pair / ground test is independent: results go to a slot of their own and are compacted in list order
+    // afterwards, so the manifold order (and everything downstream) is the same for any thread count
+    const size_t P = pairs.size();
+    const size_t G = (flags & PHYS_FLAG_GROUND_PLANE) ? bodies.size() : 0;
+    std::vector<manifold_t> found(P + G);
+#pragma omp parallel for schedule(static) num_threads(threads) if (threads > 1)
+    for (long long k = 0; k < (long long)(P + G); ++k) {
+        manifold_t& m = found[(size_t)k];
         clip_ws_t ws;
-        collide_pair(&ga, &gb, margin, &m, &ws);
-        if (m.count > 0) {
-            Manifold M{a, b, m.normal, m.count, {m.pt[0], m.pt[1], m.pt[2], m.pt[3]}, {m.depth[0], m.depth[1], m.depth[2], m.depth[3]}};
-            manifolds.push_back(M);
-            n_contacts += (uint64_t)m.count;
-        }
-    }
-    if (flags & PHYS_FLAG_GROUND_PLANE) {
-        for (size_t i = 0; i < bodies.size(); ++i) {
+        m.count = 0;
+        if ((size_t)k < P) {
+            const uint32_t a = pairs[(size_t)k].first, b = pairs[(size_t)k].second;
+            const geom_t ga = geom_of(bodies[a], &half_extent[3 * a], shape_type[a]);
+            const geom_t gb = geom_of(bodies[b], &half_extent[3 * b], shape_type[b]);
+            collide_pair(&ga, &gb, margin, &m, &ws);
+        } else {
+            const size_t i = (size_t)k - P;
             if (shape_type[i] == PHYS_SHAPE_NONE) continue;
             const geom_t ga = geom_of(bodies[i], &half_extent[3 * i], shape_type[i]);
-            manifold_t m;
-            clip_ws_t ws;
             collide_ground(&ga, ground, margin, &m, &ws);
-            if (m.count > 0) {
-                Manifold M{(uint32_t)i, PHYS_GROUND_ID, m.normal, m.count, {m.pt[0], m.pt[1], m.pt[2], m.pt[3]}, {m.depth[0], m.depth[1], m.depth[2], m.depth[3]}};
-                manifolds.push_back(M);
-                n_contacts += (uint64_t)m.count;
-            }
         }
+    }
+    for (size_t k = 0; k < P + G; ++k) {
+        const manifold_t& m = found[k];
+        if (m.count <= 0) continue;
+        const uint32_t a = k < P ? pairs[k].first : (uint32_t)(k - P);
+        const uint32_t b = k < P ? pairs[k].second : PHYS_GROUND_ID;
+        Manifold M{a, b, m.normal, m.count, {m.pt[0], m.pt[1], m.pt[2], m.pt[3]}, {m.depth[0], m.depth[1], m.depth[2], m.depth[3]}};
+        manifolds.push_back(M);
+        n_contacts += (uint64_t)m.count;
     }
 }
 
@@ -210,7 +227,9 @@ void CollisionWorld::solve(std::vector<RigidBody>& bodies, float dt) {
     // world-frame inverse inertia, the reference's convention (quirk Q5): constant, never rotated
     std::vector<m33> inv_inertia(bodies.size());
     std::vector<float> inv_mass(bodies.size());
-    for (size_t i = 0; i < bodies.size(); ++i) {
+#pragma omp parallel for schedule(static) num_threads(threads) if (threads > 1)
+    for (long long ii = 0; ii < (long long)bodies.size(); ++ii) {
+        const size_t i = (size_t)ii;
         m33 I;
         for (int k = 0; k < 9; ++k) I.m[k] = bodies[i].inertia_tensor[k];
         if (!m33_try_inverse(&I, &inv_inertia[i]))
@@ -219,7 +238,9 @@ void CollisionWorld::solve(std::vector<RigidBody>& bodies, float dt) {
     }
     std::vector<solver_manifold_t> rows(M);
     const m33 zero{};
-    for (size_t m = 0; m < M; ++m) {
+#pragma omp parallel for schedule(static) num_threads(threads) if (threads > 1)
+    for (long long mm = 0; mm < (long long)M; ++mm) {
+        const size_t m = (size_t)mm;
         const Manifold& mf = manifolds[m];
         manifold_t g;
         g.normal = mf.normal; g.count = mf.count;
@@ -233,8 +254,12 @@ void CollisionWorld::solve(std::vector<RigidBody>& bodies, float dt) {
     std::vector<std::vector<size_t>> by_color(n_colors);
     for (size_t m = 0; m < M; ++m) by_color[color[m]].push_back(m);
     for (uint32_t it = 0; it < iterations; ++it)
-        for (uint32_t c = 0; c < n_colors; ++c)
-            for (size_t m : by_color[c]) {
+        for (uint32_t c = 0; c < n_colors; ++c) {
+            // the manifolds of one colour touch disjoint bodies: any order, any number of threads, same bits
+            const std::vector<size_t>& cls = by_color[c];
+#pragma omp parallel for schedule(static) num_threads(threads) if (threads > 1 && cls.size() >= 64)
+            for (long long q = 0; q < (long long)cls.size(); ++q) {
+                const size_t m = cls[(size_t)q];
                 const Manifold& mf = manifolds[m];
                 const int has_b = mf.b != PHYS_GROUND_ID;
                 RigidBody& A = bodies[mf.a];
@@ -251,6 +276,7 @@ void CollisionWorld::solve(std::vector<RigidBody>& bodies, float dt) {
                     B.angular_velocity[0] = wB.x; B.angular_velocity[1] = wB.y; B.angular_velocity[2] = wB.z;
                 }
             }
+        }
 }
 
 void CollisionWorld::collide_and_solve(std::vector<RigidBody>& bodies, float dt) {

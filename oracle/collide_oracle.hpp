@@ -32,6 +32,7 @@ struct CollisionWorld {
     uint32_t flags = 0;
     float margin = 0.02f, ground = 0.0f;
     uint32_t iterations = 8;
+    int threads = 1;  // > 1: OpenMP over the loops whose iterations are independent (same results, bit for bit)
     solve_params_t sp{};
 
     std::vector<float> aabb;  // 6n

@@ -48,6 +48,15 @@ int32_t oracle_create(const phys_config* cfg, int32_t trig /*0 libm, 1 det*/, or
 
 int32_t oracle_destroy(oracle_world* w) { delete w; return PHYS_OK; }
 
+// OpenMP variant of the CPU baseline: `threads` > 1 runs the loops of the collision stages
+// whose iterations are independent (narrow phase per pair, row preparation, the manifolds of one colour) on that
+// many threads. The results do not depend on it (tests/test_oracle_golden.py).
+int32_t oracle_set_threads(oracle_world* w, int32_t threads) {
+    if (!w || threads < 1) return fail(PHYS_ERR_INVALID_ARG, "threads must be >= 1");
+    w->col.threads = threads;
+    return PHYS_OK;
+}
+
 int32_t oracle_set_bodies(oracle_world* w, uint64_t n, const float* pos, const float* rot, const float* lin,
                           const float* ang, const float* mass, const float* inertia, const uint32_t* shape_type,
                           const float* half_extent) {

@@ -150,3 +150,25 @@ def test_cg_many_constraints_converges_and_warm_starts():
     w.update(DT)
     assert w.get_stats().cg_converged == 1
     assert len(lam0) == 3 * n and np.isfinite(w.get_lambda()).all()
+
+
+def test_openmp_variant_of_the_oracle_gives_the_same_bits():
+    """bench.py's cpu_baseline also times the oracle with OpenMP over the independent loops of the collision stages
+    (SURVEY.md section 8 row D). The results must not depend on the thread count: a 12x3x12 block of cubes through its
+    landing (the colour classes then hold 144 manifolds and more: the threaded solver loop is exercised too)."""
+    import numpy as np
+    from oracle import binding as ob
+    from physics_amd import scenes
+    sc = scenes.falling_cubes(12, 3, 12, "omp_block")
+    out = []
+    for threads in (1, 4):
+        w = ob.OracleWorld(sc.config(), trig=ob.TRIG_DET)
+        sc.populate(w)
+        w.set_threads(threads)
+        w.update_n(scenes.DT_NANOS, 120)
+        st = w.get_stats()
+        out.append((w.get_transforms(), w.get_velocities(), (st.n_pairs, st.n_manifolds, st.n_contacts, st.n_colors)))
+        w.close()
+    assert out[0][2] == out[1][2] and out[0][2][1] > 0
+    for x, y in zip(out[0][0] + out[0][1], out[1][0] + out[1][1]):
+        assert np.array_equal(x, y)
