@@ -363,3 +363,46 @@ def test_every_step_under_a_concurrent_gemm():
             assert (sa.n_pairs, sa.n_manifolds, sa.n_contacts) == (sb.n_pairs, sb.n_manifolds, sb.n_contacts), f"step {step}"
     for x, y in zip(busy.get_transforms() + busy.get_velocities(), quiet.get_transforms() + quiet.get_velocities()):
         assert np.array_equal(x, y)
+
+
+def test_frozen_scene_gives_the_same_manifolds_every_step_under_a_concurrent_gemm():
+    """The collision stages with time taken out (tools/frozen_probe.py as a test): a settled C2 stack in a world with
+    zero gravity, zero velocities and zero solver iterations never moves, so every step must produce the manifolds of
+    the first step, bit for bit - here with a bf16 GEMM on a second stream before every step. With packed fp32
+    instructions in the narrow phase 1-6 steps in 400 did not (16 manifolds each, clip planes off by 1e-4):
+    DESIGN.md section 8."""
+    import torch
+    import physics_amd
+    from physics_amd import scenes
+    sc = scenes.c2()
+    rolled = physics_amd.World(sc.config())
+    sc.populate(rolled)
+    rolled.update_n(DT, 120)
+    rolled.sync()
+    pos, rot = rolled.get_transforms()
+    frozen = physics_amd.World(sc.config(gravity_force=(0.0, 0.0, 0.0), solver_iterations=0))
+    frozen.set_bodies(pos, rot=rot, shape_type=sc.shape_type, half_extent=sc.half_extent)
+
+    def snapshot():
+        ids, cnt, nrm, pts = frozen.get_manifolds()
+        order = np.argsort(ids[:, 0].astype(np.uint64) << np.uint64(32) | ids[:, 1])
+        live = np.arange(4)[None, :] < cnt[order][:, None]
+        return ids[order], cnt[order], nrm[order], np.where(live[..., None], pts[order], 0)
+
+    frozen.update(DT)
+    frozen.sync()
+    first = snapshot()
+    assert len(first[0]) > 5000
+    side = torch.cuda.Stream()
+    m = torch.randn(2048, 2048, device="cuda", dtype=torch.bfloat16)
+    for step in range(2, 401):
+        with torch.cuda.stream(side):
+            m2 = m @ m
+            m3 = m2 @ m
+        frozen.update(DT)
+        frozen.sync()
+        torch.cuda.synchronize()
+        for got, want in zip(snapshot(), first):
+            assert got.shape == want.shape and np.array_equal(got, want), f"step {step}"
+    p1, r1 = frozen.get_transforms()
+    assert np.array_equal(p1, pos) and np.array_equal(r1, rot)
