@@ -2,41 +2,54 @@
 """bench.py — throughput of the per-frame rigid-body step (phys_update) on MI355X.
 
 A "step" is one PhysicsState::update over one synthetic scene resident in HBM (SURVEY.md §8 row D).
-N = 1 workload: BASELINE.json configs[1] = C2, 10 000 falling cubes + ground contacts, f32. The scene is
-pre-rolled (untimed, part of set-up) until the pile is in contact, so the timed steps carry contacts; by default
-1000 steps are timed, during which the pile collapses and the contact count doubles.
-N > 1: weak scaling; every rank owns one C2-shaped slab placed side by side along x, the broad phase
-exchanges boundary AABBs with one RCCL all-gather per step, narrow phase + solver stay on owned bodies.
 
-Prints ONE JSON line (rank 0). `value` = bodies * steps / seconds over all ranks (whole-job aggregate);
-`steps_per_sec` is the plain reference-style figure. `roofline` describes the dominant kernel of the
-timed workload, timed live with HIP events on the library's own stream (phys_profile_*) in a second,
-separate pass of K steps; `cpu_baseline` is the CPU oracle (a single-threaded C++ restatement; the Rust
-reference cannot be built here) timed on the host cores on a bounded sample of the same trajectory.
+N = 1 workload: C5 = BASELINE.json configs[4], the 256k stacked-box tower: the LARGEST single-GPU configuration
+(BASELINE.json's metric is not quoted on one config). The other single-GPU configs (the 1M-cube north_star target,
+C3, C2) follow as sub-records under "other_workloads", each with its own timing, roofline and CPU sample.
+
+Timing: the window [preroll + W warm-up steps, then EXACTLY K timed steps] is repeated `--reps` times (default 5),
+every repetition on a freshly created world stepped from the same initial scene, so every repetition times the
+very same K steps of the same trajectory (the step is deterministic: bit-identical states). `value` comes from the
+MEDIAN repetition; min / max are reported beside it. Each timed region is bracketed by barrier +
+torch.cuda.synchronize() + phys_sync on both sides; with several ranks the time of a repetition is the MAX over ranks.
+
+N > 1 (`--gpus N`): weak scaling; every rank owns one workload-shaped slab placed side by side along x, the broad
+phase exchanges boundary AABBs with one RCCL all-gather per step (one process per GPU). Started without a
+launcher (no WORLD_SIZE in the environment) this script starts the N ranks itself, BEFORE anything touches the GPU.
+
+Prints ONE JSON line (rank 0). `roofline` describes the dominant kernel of the timed window, timed live with HIP
+events on the library's own stream (phys_profile_*) over the SAME window on one more fresh world. `traffic` and
+`avg_kernel_us_rocprofv3` come from the committed rocprofv3 passes of `bench.py --profile-window` and are emitted
+only when that pass covered the same window at the same scene state (profiles/r2_<workload>_window.json says which),
+otherwise null. `cpu_baseline` is the CPU oracle (a scalar C++ restatement; the Rust reference cannot be built here)
+seeded with the GPU world's state at the start of the timed window and timed on the host cores for a few steps.
 """
 import argparse
 import json
 import os
+import statistics
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s achievable
+PROFILE_ROUND = "r2"
 
 KERNEL_OF_STAGE = {
     "step_full": "k_step_full", "velocity_aabb": "k_step_velocity_aabb",
     "grid": "k_cell_insert",  # small scenes; larger ones: k_cell_assign + scan + k_scatter
     "pairs": "k_find_pairs", "narrow": "k_narrowphase",
     "color": "k_color_small",  # small scenes; larger ones: k_color_round x rounds + k_color_finish
-    "rows": "k_rows_build",    # + k_color_hist / k_color_offsets / k_color_place beyond 24k manifolds
-    "solve": "k_solve_color",
+    "rows": "k_rows_build",    # + k_color_hist / k_color_offsets / k_color_place beyond 40k manifolds
+    "solve": "k_solve_color",  # k_solve_color_quad (four lanes per manifold) unless PHYS_DEBUG_COLOR_KERNEL=lane
     "solve_tail": "k_solve_tail", "solve_flow": "k_solve_flow", "position": "k_step_position",
 }
+
+DEFAULT_PREROLL = {"c1": 100, "c2": 150, "c3": 150, "c5": 30, "t1m": 100, "c4": 0}
 
 
 def stage_bytes(stage, st, iters):
@@ -68,39 +81,42 @@ def stage_bytes(stage, st, iters):
 
 
 def _kernel_matches(name, kernel):
-    """Row name of a rocprofv3 table vs a kernel family: k_solve_flow also covers its k_solve_flow_quad variant."""
+    """Kernel name of a profile table vs a kernel family: k_solve_flow also covers k_solve_flow_quad, k_solve_color
+    also k_solve_color_quad."""
     base = name.split("(")[0].split("<")[0].replace("void ", "").strip().split("::")[-1]
     return base == kernel or base.startswith(kernel + "_")
 
 
-def rocprof_avg_us(workload_key, kernel):
-    """(kernel name, average duration in us) from the committed rocprofv3 --kernel-trace run of this same script:
-    the per-kernel statistics of the launches of its profile pass (profiles/r1_<workload>_profile_pass_stats.csv,
-    cut out of the trace by tools/trace_tail.py; the whole-run --stats summary is r1_<workload>_kernel_stats.csv).
-    HIP-event brackets (avg_launch_us) additionally contain the dispatch of the launch (about 2-4 us per launch)."""
-    import csv
-    for name in (f"r1_{workload_key}_profile_pass_stats.csv", f"r1_{workload_key}_kernel_stats.csv"):
-        path = os.path.join(ROOT, "profiles", name)
-        if not os.path.exists(path):
-            continue
-        rows = [r for r in csv.DictReader(open(path)) if _kernel_matches(r["Name"], kernel)]
-        if rows:
-            r = max(rows, key=lambda r: int(r["Calls"]))
-            return r["Name"].split("(")[0].replace("void ", "").strip().split("::")[-1], round(float(r["AverageNs"]) / 1e3, 3)
-    return None, None
-
-
-def pmc_traffic(workload_key, kernel):
-    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/pmc_traffic.json, produced by
-    profiles/collect_pmc.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same script)."""
-    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+def committed_window(workload_key):
+    path = os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_{workload_key}_window.json")
     if not os.path.exists(path):
         return None
-    table = json.load(open(path)).get(workload_key, {})
-    rows = [row for name, row in table.items() if isinstance(row, dict) and _kernel_matches(name, kernel)]
-    if rows:
-        return max(rows, key=lambda r: r["launches_sampled"])["traffic_bytes"]
-    return None
+    try:
+        return json.load(open(path))
+    except Exception:
+        return None
+
+
+def committed_profile_fields(workload_key, kernel, window, st):
+    """(kernel name, rocprofv3 average us, PMC traffic bytes per launch, note). The committed numbers are handed out
+    ONLY when they were taken over the same window (preroll, warm-up, steps) and the scene was in the same state
+    (manifold and colour counts equal): nothing of another state is ever mixed into one roofline object."""
+    c = committed_window(workload_key)
+    if c is None:
+        return None, None, None, f"no committed profile for this workload (profiles/{PROFILE_ROUND}_{workload_key}_window.json)"
+    cw, cs = c.get("window", {}), c.get("scene_stats", {})
+    same_window = all(cw.get(k) == window[k] for k in ("preroll", "warmup", "steps"))
+    same_state = all(cs.get(k) == st[k] for k in ("n_bodies", "n_manifolds", "n_colors"))
+    if not (same_window and same_state):
+        return None, None, None, (f"committed profile covers window {cw} at {cs.get('n_manifolds')} manifolds / "
+                                  f"{cs.get('n_colors')} colours; this run: {window} at {st['n_manifolds']} / {st['n_colors']}: "
+                                  f"not mixed in")
+    rows = [(name, r) for name, r in c.get("kernels", {}).items() if _kernel_matches(name, kernel)]
+    if not rows:
+        return None, None, None, "kernel not in the committed profile"
+    name, r = max(rows, key=lambda kv: kv[1].get("total_us", 0.0))
+    short = name.split("(")[0].replace("void ", "").strip().split("::")[-1]
+    return short, r.get("avg_us"), r.get("traffic_bytes"), f"profiles/{PROFILE_ROUND}_{workload_key}_window.json (same window, same scene state)"
 
 
 def stats_dict(s):
@@ -108,50 +124,119 @@ def stats_dict(s):
                                             "color_rounds", "n_ground_manifolds")}
 
 
-def run_timed(world, steps, dist=None, halo=None):
-    from physics_amd.scenes import DT_NANOS
+class Rig:
+    """Everything one rank needs to build its world again and again (one fresh world per repetition)."""
+
+    def __init__(self, workload, rank, world_size, local_rank, dist, rehearsal, sharded):
+        from physics_amd import scenes
+        self.workload, self.rank, self.world_size, self.local_rank = workload, rank, world_size, local_rank
+        self.dist, self.rehearsal, self.sharded = dist, rehearsal, sharded
+        self.halo = None
+        if not sharded:
+            self.scene = scenes.SCENES[workload]()
+        else:
+            from physics_amd import sharding
+            self.scene, self.halo = sharding.make_rank_scene(workload, rank, world_size, dist, local_rank, pinned_host=rehearsal)
+        self.iters = self.scene.solver_iterations
+
+    def make_world(self):
+        import physics_amd
+        w = physics_amd.World(self.scene.config(device=self.local_rank))
+        self.scene.populate(w)
+        if self.halo is not None:
+            self.halo.attach(w, self.scene)
+        return w
+
+    def advance(self, world, steps):
+        from physics_amd.scenes import DT_NANOS
+        if steps <= 0:
+            return
+        if self.halo is None:
+            world.update_n(DT_NANOS, steps)
+        else:
+            for _ in range(steps):
+                world.update(DT_NANOS)
+                self.halo.exchange(world)
+
+    def fence(self, world):
+        import torch
+        if self.dist is not None:
+            self.dist.barrier()
+        torch.cuda.synchronize()
+        world.sync()
+
+    def max_over_ranks(self, x):
+        if self.dist is None:
+            return x
+        import torch
+        t = torch.tensor([x], dtype=torch.float64, device="cpu" if self.rehearsal else f"cuda:{self.local_rank}")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def sum_over_ranks(self, x):
+        if self.dist is None:
+            return x
+        import torch
+        t = torch.tensor([x], dtype=torch.float64, device="cpu" if self.rehearsal else f"cuda:{self.local_rank}")
+        self.dist.all_reduce(t)
+        return float(t.item())
+
+
+def timed_repetition(rig, preroll, warmup, steps, want_state=False):
+    """One fresh world: preroll + warm-up (untimed), then EXACTLY `steps` timed steps. Returns (seconds = max over
+    ranks, stats after the window, state at the START of the window if asked for)."""
     import torch
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    world.sync()
+    w = rig.make_world()
+    rig.advance(w, preroll)
+    w.sync()
+    rig.advance(w, warmup)
+    state = None
+    if want_state:
+        w.sync()
+        state = w.get_transforms() + w.get_velocities()
+    rig.fence(w)
     t0 = time.perf_counter()
-    if halo is None:
-        world.update_n(DT_NANOS, steps)
-    else:
-        for _ in range(steps):
-            world.update(DT_NANOS)
-            halo.exchange(world)
-    world.sync()
+    rig.advance(w, steps)
+    w.sync()
     torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    return time.perf_counter() - t0
+    if rig.dist is not None:
+        rig.dist.barrier()
+    elapsed = rig.max_over_ranks(time.perf_counter() - t0)
+    st = stats_dict(w.get_stats())
+    cross = int(w.get_stats().n_cross_pairs) if rig.halo is not None else 0
+    w.close()
+    return elapsed, st, cross, state
 
 
-def profile_pass(world, steps, iters, workload_key="c2"):
-    """K more steps with per-launch HIP events; returns the roofline object of the dominant kernel and
-    the per-stage table."""
-    from physics_amd.scenes import DT_NANOS
-    world.sync()
-    world.profile_enable(True)
-    world.update_n(DT_NANOS, steps)
-    world.sync()
-    prof, psteps = world.profile_get()
-    world.profile_enable(False)
-    st = stats_dict(world.get_stats())
+def profile_window(rig, preroll, warmup, steps, workload_key):
+    """The SAME window once more on a fresh world, every launch bracketed by HIP events on the library's stream.
+    Returns the roofline object of the dominant kernel, the per-stage table and the scene stats after the window."""
+    w = rig.make_world()
+    rig.advance(w, preroll)
+    rig.advance(w, warmup)
+    w.sync()
+    w.profile_enable(True)
+    rig.advance(w, steps)
+    w.sync()
+    prof, psteps = w.profile_get()
+    w.profile_enable(False)
+    st = stats_dict(w.get_stats())
+    counts = [int(c) for c in w.get_color_counts()[:st["n_colors"]]]
+    w.close()
+    iters = rig.iters
     table = {}
     for stage, (ms, launches) in prof.items():
         table[stage] = {"ms_per_step": ms / max(psteps, 1), "launches_per_step": launches / max(psteps, 1),
                         "avg_launch_us": 1e3 * ms / max(launches, 1)}
     kernel_stages = [s for s in table if s in KERNEL_OF_STAGE]
+    if not kernel_stages:
+        return None, table, st
     dom = max(kernel_stages, key=lambda s: table[s]["ms_per_step"])
     b_step = stage_bytes(dom, st, iters)
     if dom == "solve" and "solve_tail" in table:
         # k_solve_color only runs the colours that got a launch of their own; the trailing small colours
         # (<= 512 manifolds each, at least two of them) are solved by k_solve_tail. Scale the stage's bytes by the
         # share of manifolds in the individually launched colours (same rule as launch_solver).
-        counts = [int(c) for c in world.get_color_counts()[:st["n_colors"]]]
         big = len(counts)
         while big > 0 and counts[big - 1] <= 512:
             big -= 1
@@ -164,16 +249,18 @@ def profile_pass(world, steps, iters, workload_key="c2"):
     dur_s = table[dom]["avg_launch_us"] * 1e-6
     achieved = per_launch / dur_s / 1e9 if dur_s > 0 else 0.0
     total_bytes = sum(stage_bytes(s, st, iters) for s in kernel_stages)
-    family = KERNEL_OF_STAGE[dom].split("+")[0]
-    prof_name, prof_us = rocprof_avg_us(workload_key, family)
-    roof = {"bound": "hbm", "kernel": prof_name or KERNEL_OF_STAGE[dom], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-            "traffic": pmc_traffic(workload_key, family),
+    family = KERNEL_OF_STAGE[dom]
+    window = {"preroll": preroll, "warmup": warmup, "steps": steps}
+    prof_name, prof_us, traffic, note = committed_profile_fields(workload_key, family, window, st)
+    roof = {"bound": "hbm", "kernel": prof_name or family, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
             "algorithmic_bytes_per_launch": int(per_launch), "avg_launch_us": round(table[dom]["avg_launch_us"], 3),
-            "avg_kernel_us_rocprofv3": prof_us,
+            "avg_kernel_us_rocprofv3": prof_us, "committed_profile": note,
             "launches_per_step": round(launches, 2), "stage_share_of_device_time": round(
                 table[dom]["ms_per_step"] / max(sum(t["ms_per_step"] for t in table.values()), 1e-12), 3),
-            "algorithmic_bytes_per_step_all_kernels": int(total_bytes)}
+            "algorithmic_bytes_per_step_all_kernels": int(total_bytes),
+            "all_kernels_achieved_gbs": round(total_bytes / max(sum(t["ms_per_step"] for t in table.values()), 1e-12) / 1e6, 1),
+            "window": window, "scene_stats_after_window": st}
     return roof, table, st
 
 
@@ -197,57 +284,119 @@ def copy_ceiling_gbs(device):
     return round(best, 1)
 
 
-def cpu_baseline(scene, preroll, sample_steps):
+def cpu_baseline(scene, state, window_start, sample_steps, budget_s=14.0):
+    """The CPU oracle on the host cores, on a bounded sample: seeded with the GPU world's state at the start of the
+    timed window (poses and velocities), one untimed step (its first colouring starts from scratch), then up to
+    `sample_steps` timed steps or `budget_s` seconds, whichever comes first. One thread, then all host cores (OpenMP)."""
     from oracle import binding as ob
     from physics_amd.scenes import DT_NANOS
+    pos, rot, lin, ang = state
 
     def timed(threads):
         o = ob.OracleWorld(scene.config(), trig=ob.TRIG_DET)
-        scene.populate(o)
+        o.set_bodies(pos, rot=rot, lin_vel=lin, ang_vel=ang, shape_type=scene.shape_type, half_extent=scene.half_extent)
         o.set_threads(threads)
-        o.update_n(DT_NANOS, preroll)
-        t0 = time.perf_counter()
-        o.update_n(DT_NANOS, sample_steps)
+        o.update(DT_NANOS)
+        done, t0 = 0, time.perf_counter()
+        while done < sample_steps:
+            o.update(DT_NANOS)
+            done += 1
+            if time.perf_counter() - t0 > budget_s:
+                break
         dt = time.perf_counter() - t0
         o.close()
-        return dt
+        return done, dt
 
-    dt = timed(1)
+    k1, dt = timed(1)
     # SURVEY row D: additionally the OpenMP variant of the same oracle (same bits for any thread count) on the host
     # cores this process may use, at most 16 (the CPU share of one GPU on the bench boxes)
     cores = min(len(os.sched_getaffinity(0)), 16)
-    dt_mt = timed(cores) if cores > 1 else dt
-    return {"value": round(scene.n * sample_steps / dt, 1), "unit": "body-steps/s", "cores": 1, "kind": "port",
-            "steps_per_sec": round(sample_steps / dt, 3),
-            "sample": f"oracle (scalar C++ restatement + CPU collision stages, 1 thread; the Rust reference is not "
-                      f"buildable here), same scene, steps {preroll}..{preroll + sample_steps} of the same trajectory (a "
-                      f"bounded sample: the first steps of the timed window; later steps carry more contacts)",
-            "openmp": {"value": round(scene.n * sample_steps / dt_mt, 1), "unit": "body-steps/s", "cores": cores,
-                       "steps_per_sec": round(sample_steps / dt_mt, 3),
+    km, dt_mt = timed(cores) if cores > 1 else (k1, dt)
+    return {"value": round(scene.n * k1 / dt, 1), "unit": "body-steps/s", "cores": 1, "kind": "port",
+            "steps_per_sec": round(k1 / dt, 4),
+            "sample": f"oracle (scalar C++ restatement of the reference step + CPU collision stages, 1 thread; the Rust "
+                      f"reference is not buildable here: no cargo/rustc), workload {scene.name}, seeded with the GPU world's "
+                      f"poses and velocities at step {window_start} (start of the timed window), 1 untimed step, then "
+                      f"{k1} timed steps",
+            "openmp": {"value": round(scene.n * km / dt_mt, 1), "unit": "body-steps/s", "cores": cores,
+                       "steps_per_sec": round(km / dt_mt, 4), "steps_timed": km,
                        "note": "same oracle, same sample, OpenMP over the independent loops of the collision stages "
                                "(AABBs, grid search, narrow phase, row preparation, the manifolds of one colour); the "
                                "reference itself is single-threaded"}}
 
 
+def measure_workload(rig, args, preroll, reps, with_cpu):
+    """Timed repetitions + profile window + (optionally) CPU sample of one workload on this rank's rig."""
+    times, st, cross, state = [], None, 0, None
+    for r in range(reps):
+        e, st, cross, s = timed_repetition(rig, preroll, args.warmup, args.steps, want_state=(with_cpu and r == 0))
+        times.append(e)
+        if s is not None:
+            state = s
+    med = statistics.median(times)
+    n_total = rig.scene.n * rig.world_size
+    pairs_total = rig.sum_over_ranks(float(st["n_pairs"] + cross))
+    rec = {
+        "value": round(n_total * args.steps / med, 1), "steps_per_sec": round(args.steps / med, 2),
+        "ms_per_step": round(1e3 * med / args.steps, 4),
+        "repetitions": {"n": reps, "statistic": "median",
+                        "steps_per_sec": [round(args.steps / t, 2) for t in times],
+                        "min_steps_per_sec": round(args.steps / max(times), 2),
+                        "max_steps_per_sec": round(args.steps / min(times), 2),
+                        "every_repetition": "fresh world, same scene, same preroll + warm-up: the same K steps of the same trajectory"},
+        "pairs_per_sec": round(pairs_total * args.steps / med, 1),
+        "scene_stats": st, "n_bodies": n_total, "preroll": preroll,
+    }
+    # sharded: every rank steps through the profile window (the exchange is a collective); rank 0 reports its slab
+    roof, table = None, {}
+    if rig.rank == 0 or rig.sharded:
+        roof, table, _ = profile_window(rig, preroll, args.warmup, args.steps, rig.workload)
+    if rig.rank == 0:
+        if roof is not None:
+            rec["roofline"] = roof
+            rec["stages"] = {k: {kk: round(vv, 3) for kk, vv in v.items()} for k, v in table.items()}
+        if with_cpu and state is not None:
+            rec["cpu_baseline"] = cpu_baseline(rig.scene, state, preroll + args.warmup, args.cpu_steps)
+    return rec
+
+
+def spawn_ranks(n, argv):
+    """`bench.py --gpus N` without a launcher: start the N rank processes (one per GPU) as children of this one,
+    before anything here has touched torch or the GPU, and pass their output and exit code through."""
+    port = os.environ.get("MASTER_PORT", "29517")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", port, os.path.abspath(__file__)] + argv
+    return subprocess.call(cmd)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=-1, help="timed steps (default: 1000 for c1 / c2, 200 otherwise: SURVEY.md §8 D)")
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", default="c2", choices=["c1", "c2", "c3", "c5", "t1m", "c4"])
-    ap.add_argument("--preroll", type=int, default=-1, help="untimed set-up steps (default per workload)")
+    ap.add_argument("--steps", type=int, default=20, help="timed steps K per repetition")
+    ap.add_argument("--warmup", type=int, default=5, help="untimed warm-up steps W in front of the K timed ones")
+    ap.add_argument("--reps", type=int, default=5, help="repetitions of the timed window (median reported)")
+    ap.add_argument("--workload", default="c5", choices=["c1", "c2", "c3", "c5", "t1m", "c4"])
+    ap.add_argument("--preroll", type=int, default=-1, help="untimed set-up steps in front of the warm-up (default per workload)")
+    ap.add_argument("--cpu-steps", type=int, default=4, help="timed oracle steps of the CPU sample (bounded by 14 s per variant)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extra", action="store_true", help="skip the 1M-body target run appended at N=1")
+    ap.add_argument("--no-extra", action="store_true", help="skip the other single-GPU workloads appended at N=1")
+    ap.add_argument("--profile-window", action="store_true",
+                    help="ONE world, preroll + warm-up + K steps and nothing else: the command the committed rocprofv3 "
+                         "kernel-trace / PMC passes run (tools/profile_window.py cuts the last K steps out of the trace)")
     args = ap.parse_args()
-    if args.steps < 0:
-        args.steps = 1000 if args.workload in ("c1", "c2") else 200
+
+    env_ws = os.environ.get("WORLD_SIZE")
+    if env_ws is None and args.gpus > 1:
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
+    world_size = int(env_ws or "1")
+    if world_size != args.gpus and not (args.gpus == 1 and env_ws is not None):
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world_size}: launch with matching values "
+              f"(or without a launcher: this script starts its own ranks)", file=sys.stderr)
+        sys.exit(2)
 
     import torch
-    import physics_amd
-    from physics_amd import scenes
     from physics_amd.scenes import DT_NANOS
 
-    world_size = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
@@ -275,91 +424,70 @@ def main():
         torch.cuda.set_device(local_rank)
     n_gpus = world_size
 
-    default_preroll = {"c1": 100, "c2": 150, "c3": 150, "c5": 30, "t1m": 100, "c4": 0}
-    preroll = args.preroll if args.preroll >= 0 else default_preroll[args.workload]
-    halo = None
-    if not sharded:
-        scene = scenes.SCENES[args.workload]()
-    else:
-        from physics_amd import sharding
-        scene, halo = sharding.make_rank_scene(args.workload, rank, world_size, dist, local_rank, pinned_host=rehearsal)
-    world = physics_amd.World(scene.config(device=local_rank))
-    scene.populate(world)
-    if halo is not None:
-        halo.attach(world, scene)
-    iters = scene.solver_iterations
+    preroll = args.preroll if args.preroll >= 0 else DEFAULT_PREROLL[args.workload]
+    rig = Rig(args.workload, rank, world_size, local_rank, dist, rehearsal, sharded)
 
-    # set-up (untimed): reach the contact-rich state, then W warm-up steps
-    world.update_n(DT_NANOS, preroll)
-    world.sync()
-    if halo is None:
-        world.update_n(DT_NANOS, args.warmup)
-    else:
-        for _ in range(args.warmup):
-            world.update(DT_NANOS)
-            halo.exchange(world)
-    world.sync()
+    if args.profile_window:
+        w = rig.make_world()
+        rig.advance(w, preroll)
+        rig.advance(w, args.warmup)
+        w.sync()
+        rig.advance(w, args.steps)
+        w.sync()
+        st = stats_dict(w.get_stats())
+        w.close()
+        if rank == 0:
+            print(json.dumps({"profile_window": {"workload": args.workload, "preroll": preroll, "warmup": args.warmup,
+                                                 "steps": args.steps}, "scene_stats": st}))
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
-    elapsed = run_timed(world, args.steps, dist, halo)
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else f"cuda:{local_rank}")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    st = stats_dict(world.get_stats())
-    n_total = scene.n * n_gpus
-    pairs_local = st["n_pairs"] + (int(world.get_stats().n_cross_pairs) if halo is not None else 0)
-    if dist is not None:
-        t = torch.tensor([pairs_local], dtype=torch.float64, device="cpu" if rehearsal else f"cuda:{local_rank}")
-        dist.all_reduce(t)
-        pairs_total = float(t.item())
-    else:
-        pairs_total = float(pairs_local)
+    with_cpu = rank == 0 and not sharded and not args.no_cpu_baseline
+    rec = measure_workload(rig, args, preroll, args.reps, with_cpu)
 
     out = None
     if rank == 0:
-        # rank 0 profiles its own slab (no collective inside: the other ranks wait at the final barrier)
-        roof, table, st2 = profile_pass(world, min(args.steps, 100), iters, args.workload)
         out = {
-            "metric": "rigid_body_steps_per_sec", "value": round(n_total * args.steps / elapsed, 1),
+            "metric": "rigid_body_steps_per_sec", "value": rec["value"],
             "unit": "body-steps/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": rec["ms_per_step"], "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": scene.name, "n_bodies": n_total, "bodies_per_gpu": scene.n,
-                       "solver_iterations": iters, "dt_nanos": DT_NANOS, "preroll_steps": preroll,
-                       "sharding": "none" if not sharded else f"x-slabs x{n_gpus}, halo all-gather per step"},
-            "steps_per_sec": round(args.steps / elapsed, 2),
-            "pairs_per_sec": round(pairs_total * args.steps / elapsed, 1),
-            "scene_stats": st,
+            "config": {"workload": rig.scene.name, "n_bodies": rec["n_bodies"], "bodies_per_gpu": rig.scene.n,
+                       "solver_iterations": rig.iters, "dt_nanos": DT_NANOS, "preroll_steps": preroll,
+                       "timed_window": f"steps {preroll + args.warmup}..{preroll + args.warmup + args.steps} of the trajectory",
+                       "sharding": "none" if not sharded else f"x-slabs x{n_gpus}, one process per GPU, halo all-gather per step",
+                       "rccl_ranks": n_gpus if sharded and not rehearsal else (0 if not sharded else f"{n_gpus} (gloo rehearsal on one GPU)")},
+            "steps_per_sec": rec["steps_per_sec"], "repetitions": rec["repetitions"],
+            "pairs_per_sec": rec["pairs_per_sec"], "scene_stats": rec["scene_stats"],
         }
-        if roof is not None:
+        if sharded:
+            out["config"]["cross_slab_contacts"] = ("candidate pairs across slab faces are found and counted (halo exchange), "
+                                                    "not collided or solved: each rank's narrow phase and solver see owned "
+                                                    "bodies only, so the N-rank run is N slab simulations + the exchange, "
+                                                    "not the single-world simulation cut in N")
+        if "roofline" in rec:
+            roof = rec["roofline"]
             if not sharded:
                 roof["copy_ceiling"] = copy_ceiling_gbs(f"cuda:{local_rank}")  # GB/s a device-to-device copy reaches here
                 roof["frac_of_copy_ceiling"] = round(roof["achieved"] / roof["copy_ceiling"], 5)
             out["roofline"] = roof
-            out["stages"] = {k: {kk: round(vv, 3) for kk, vv in v.items()} for k, v in table.items()}
-    elif halo is None:
-        pass
-    world.close()
+            out["stages"] = rec["stages"]
+        if "cpu_baseline" in rec:
+            out["cpu_baseline"] = rec["cpu_baseline"]
 
-    if rank == 0 and not sharded:
-        if not args.no_cpu_baseline:
-            sample = 200 if args.workload in ("c1", "c2") else 10
-            out["cpu_baseline"] = cpu_baseline(scene, preroll, sample)
-        if not args.no_extra and args.workload == "c2":
-            # north_star target: >= 1M bodies at >= 60 steps/s on one MI355X
-            sc = scenes.target_1m()
-            w = physics_amd.World(sc.config(device=local_rank))
-            sc.populate(w)
-            w.update_n(DT_NANOS, 100)
-            w.sync()
-            k = 60
-            e = run_timed(w, k)
-            roof1, table1, st1 = profile_pass(w, 20, sc.solver_iterations, "t1m")
-            out["target_1m"] = {"workload": sc.name, "n_bodies": sc.n, "preroll_steps": 100, "steps": k,
-                                "steps_per_sec": round(k / e, 2), "target_steps_per_sec": 60.0,
-                                "body_steps_per_sec": round(sc.n * k / e, 1), "scene_stats": st1, "roofline": roof1,
-                                "stages": {a: {kk: round(vv, 3) for kk, vv in v.items()} for a, v in table1.items()}}
-            w.close()
+    if rank == 0 and not sharded and not args.no_extra and args.workload == "c5":
+        # the other single-GPU configurations, measured the same way (fewer repetitions: they are sub-records)
+        others = {}
+        for wl in ("t1m", "c3", "c2"):
+            r2 = Rig(wl, 0, 1, local_rank, None, False, False)
+            rr = measure_workload(r2, args, DEFAULT_PREROLL[wl], 3, not args.no_cpu_baseline)
+            rr["workload"] = r2.scene.name
+            if wl == "t1m":
+                rr["north_star_target_steps_per_sec"] = 60.0
+            others[wl] = rr
+        out["other_workloads"] = others
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -34,7 +34,8 @@ extern "C" {
 #define PHYS_ERR_NO_DEVICE (-2)
 #define PHYS_ERR_HIP (-3)
 #define PHYS_ERR_SINGULAR_INERTIA (-4) /* reference: try_inverse().unwrap() panic, rigid_body.rs:31 */
-#define PHYS_ERR_CAPACITY (-5)         /* pair / manifold buffer overflow (sticky until reset) */
+#define PHYS_ERR_CAPACITY (-5)         /* pair / manifold / halo buffer overflow, or more than 64 manifolds at one body;
+                                          raised in ANY step since the last phys_sync (sticky), cleared by that phys_sync */
 #define PHYS_ERR_OUT_OF_RANGE (-6)     /* body index out of range (reference: Vec index panic) */
 #define PHYS_ERR_UNSUPPORTED (-7)
 #define PHYS_ERR_NO_BODIES (-8)        /* reference: view() panic on N = 0 */
@@ -84,7 +85,8 @@ typedef struct phys_stats {
     uint32_t cg_iterations; /* CG iterations of the last constraint solve */
     int32_t cg_converged;   /* 1 = Some(lambda), 0 = None (sle_solver.rs:45) */
     uint64_t steps;         /* updates since creation */
-    uint32_t overflow;      /* sticky capacity overflow flags */
+    uint32_t overflow;      /* bit 0 pairs, 1 manifolds, 2 colours (> 64 manifolds at one body), 3 halo / cross pairs,
+                               4 solver hand-off timeout: the last update's bits OR every bit raised since the last phys_sync */
     uint32_t n_ground_manifolds; /* manifolds against the ground plane (subset of n_manifolds) */
     float max_extent;       /* largest fattened-AABB edge of the last broad phase (the grid cell is 1.001x this) */
     uint32_t n_halo_records; /* records written by the last phys_halo_pack */
@@ -133,7 +135,11 @@ int32_t phys_apply_gravity(phys_world* w);
 int32_t phys_step(phys_world* w, uint64_t dt_nanos);
 /* n updates back to back without returning to the host in between (same result as n phys_update) */
 int32_t phys_update_n(phys_world* w, uint64_t dt_nanos, uint32_t n);
-/* block until all queued device work of this world is done; reports sticky device-side errors */
+/* block until all queued device work of this world is done. Device-side errors are sticky: a capacity overflow or a
+ * solver time-out in ANY update since the previous phys_sync (also an early one of a phys_update_n batch) is reported
+ * here once - PHYS_ERR_CAPACITY / PHYS_ERR_HIP - and then cleared. The contact solve of an overflowing update is
+ * skipped (never run on a truncated contact set); bodies are still integrated.
+ * Limit: at most 64 contact manifolds per body (one solver colour each). */
 int32_t phys_sync(phys_world* w);
 
 /* body.position / body.rotation reads (physics.rs:64-65); synchronous device-to-host */

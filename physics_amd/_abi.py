@@ -165,6 +165,50 @@ class PhysicsHipMissing(RuntimeError):
     pass
 
 
+def rocm_runtime_mapped():
+    """Paths of the HIP runtime(s) mapped into this process (one entry in a healthy process)."""
+    try:
+        return sorted({line.split()[-1] for line in open("/proc/self/maps") if "libamdhip64" in line})
+    except OSError:
+        return []
+
+
+def torch_bundled_rocm_dir():
+    """Directory of the ROCm runtime a PyTorch wheel ships inside itself, found WITHOUT importing torch."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return None
+    if spec is None or not spec.origin:
+        return None
+    d = os.path.join(os.path.dirname(spec.origin), "lib")
+    return d if os.path.exists(os.path.join(d, "libamdhip64.so")) else None
+
+
+def share_rocm_runtime_with_torch():
+    """One ROCm runtime per process. The PyTorch wheel of this image ships its OWN libamdhip64.so / libhsa-runtime64.so
+    (ROCm 7.0.2, under torch/lib, SONAME libamdhip64.so.7) next to the system's /opt/rocm (7.2.0, same SONAME).
+    libphysics_hip.so asks for the SONAME, libtorch_hip.so for the file in its own directory, so the order of loading
+    decided what a process got: torch first -> ONE runtime (torch's, found again by SONAME); the library first -> /opt/rocm's
+    for the library and then a SECOND runtime for torch, whose initialisation fails with hipErrorNoDevice ("no ROCm-capable
+    device is detected", round 1's unexplained failure: two HSA runtimes cannot both own the process's KFD queue state).
+    So when a PyTorch with a bundled runtime is installed and no HIP runtime is mapped yet, that bundled runtime is
+    loaded first (RTLD_GLOBAL, by path - torch itself need not be imported): library and torch then share it whichever
+    comes first. Callers without PyTorch (the Rust / C++ hosts) get the system runtime, alone in its process.
+    PHYS_ROCM_RUNTIME=system skips this (a process that will never import torch)."""
+    if os.environ.get("PHYS_ROCM_RUNTIME") == "system" or rocm_runtime_mapped():
+        return None
+    d = torch_bundled_rocm_dir()
+    if d is None:
+        return None
+    for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+        path = os.path.join(d, name)
+        if os.path.exists(path):
+            C.CDLL(path, mode=C.RTLD_GLOBAL)
+    return d
+
+
 def load_library():
     """Load libphysics_hip.so (built in-tree by __graft_entry__.build()). Raises if absent: the
     product path has no CPU fallback."""
@@ -175,6 +219,7 @@ def load_library():
         raise PhysicsHipMissing(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). physics_amd has no CPU fallback.")
+    share_rocm_runtime_with_torch()
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol

@@ -60,6 +60,7 @@ void poll_snapshots(phys_world* w) {
         }
         const StepCounters& c = *w->h_snap[k];
         w->snap_pending[k] = false;
+        w->host_sticky_overflow |= c.overflow | c.sticky_overflow;  // latched until phys_sync reports it
         if (c.overflow) continue;
         w->hint.valid = true;
         w->hint.n_manifolds = c.n_manifolds;
@@ -157,7 +158,7 @@ int32_t phys_destroy(phys_world* w) {
     DevBuf<float>* fb[] = {&w->pos, &w->rot, &w->vel, &w->force, &w->torque, &w->inv_inertia_diag,
                            &w->inv_inertia, &w->half_extent, &w->aabb, &w->cg_x, &w->cg_r, &w->cg_p, &w->cg_ap,
                            &w->cg_rhs, &w->cg_c, &w->cg_scratch, &w->man_normal, &w->man_points, &w->row_n,
-                           &w->row_pt, &w->row_tb, &w->row_acc, &w->flow_vel, &w->sorted_box, &w->slot_box};
+                           &w->row_pt, &w->row_tb, &w->row_acc, &w->row_all, &w->flow_vel, &w->sorted_box, &w->slot_box};
     for (auto* b : fb) b->free();
     DevBuf<uint32_t>* ub[] = {&w->shape, &w->global_id, &w->cg_status, &w->bucket_of, &w->bucket_count,
                               &w->bucket_start, &w->bucket_cursor, &w->sorted_ids, &w->slot_ids, &w->grid_ovf, &w->scan_block_sums, &w->pairs,
@@ -376,14 +377,37 @@ static int32_t fetch_counters(phys_world* w) {
     return PHYS_OK;
 }
 
+// Device-side errors are STICKY: every overflow bit raised by any step since the last phys_sync is reported here
+// (StepCounters::sticky_overflow; the per-step word is zeroed by the next step), then cleared.
 int32_t phys_sync(phys_world* w) {
     ENTER(w);
     const int32_t rc = fetch_counters(w);
     if (rc != PHYS_OK) return rc;
-    if (w->h_counters->overflow & 16u)
-        return fail(PHYS_ERR_HIP, "contact solver hand-off timed out (k_solve_flow); velocities of this step are invalid");
-    if (w->h_counters->overflow)
-        return fail(PHYS_ERR_CAPACITY, "pair/manifold/colour capacity exceeded: raise phys_config.max_pairs / max_manifolds");
+    poll_snapshots(w);  // the stream is idle: every snapshot in flight is adopted now, none can bring reported bits back later
+    const uint32_t bits = w->h_counters->overflow | w->h_counters->sticky_overflow | w->host_sticky_overflow;
+    w->host_sticky_overflow = 0;
+    if (w->h_counters->sticky_overflow) {
+        PHYS_HIP_TRY(hipMemsetAsync(&w->counters.p->sticky_overflow, 0, sizeof(uint32_t), w->stream));
+        PHYS_HIP_TRY(hipStreamSynchronize(w->stream));
+    }
+    if (bits & 32u) {
+        const uint32_t* g = w->h_counters->debug;
+        return fail(PHYS_ERR_HIP, ("internal error: a solver row names no body of this world and was refused (row " +
+                                   std::to_string(g[0]) + ": a " + std::to_string(g[1]) + ", b " + std::to_string(g[2]) + ", points " +
+                                   std::to_string(g[3]) + "; colour " + std::to_string(g[6]) + " rows [" + std::to_string(g[4]) + ", " +
+                                   std::to_string(g[5]) + "), tile base " + std::to_string(g[7]) + ")").c_str());
+    }
+    if (bits & 16u)
+        return fail(PHYS_ERR_HIP, "contact solver hand-off timed out (k_solve_flow) in a step since the last phys_sync; "
+                                  "velocities are invalid from that step on");
+    if (bits & 4u)
+        return fail(PHYS_ERR_CAPACITY, "a body has more than 64 contact manifolds (PHYS_MAX_COLORS): the contact solve of "
+                                       "that step was skipped. This limit is not configurable");
+    if (bits & 8u)
+        return fail(PHYS_ERR_CAPACITY, "halo record / cross-pair capacity exceeded in a step since the last phys_sync");
+    if (bits)
+        return fail(PHYS_ERR_CAPACITY, "pair / manifold capacity exceeded in a step since the last phys_sync (the contact "
+                                       "solve of that step was skipped): raise phys_config.max_pairs / max_manifolds");
     return PHYS_OK;
 }
 
@@ -517,7 +541,7 @@ int32_t phys_get_stats(phys_world* w, phys_stats* out) {
         out->cg_iterations = w->steps ? 1u : 0u;
     }
     out->steps = w->steps;
-    out->overflow = c.overflow;
+    out->overflow = c.overflow | c.sticky_overflow | w->host_sticky_overflow;  // last step's bits + everything since the last phys_sync
     out->n_ground_manifolds = c.n_ground_manifolds;
     std::memcpy(&out->max_extent, &c.max_extent_bits, 4);
     out->n_halo_records = c.n_halo;

@@ -286,7 +286,7 @@ __device__ __forceinline__ void stage_flush(PairStage& st, uint32_t* __restrict_
     if (lane == 0) base = atomicAdd(&ctr->n_pairs, st.count);
     base = (uint32_t)__shfl((int)base, 0, 64);
     if ((uint64_t)base + st.count > max_pairs) {
-        if (lane == 0) atomicOr(&ctr->overflow, 1u);
+        if (lane == 0) flag_overflow(ctr, 1u);
     }
     for (uint32_t k = lane; k < st.count; k += 64) {
         const uint64_t dst = (uint64_t)base + k;
@@ -536,8 +536,8 @@ int32_t collision_alloc(phys_world* w) {
         w->color_state.point_at(reinterpret_cast<unsigned long long*>(w->step_zero.p + b_bytes), c_bytes / 8);
         w->counters.point_at(reinterpret_cast<StepCounters*>(w->step_zero.p + b_bytes + c_bytes), 1);
         w->step_zero_reset_bytes = b_bytes + c_bytes + kCountersStepResetBytes;
-        w->step_zero_full_bytes = b_bytes + c_bytes + sizeof(StepCounters);
-        PHYS_HIP_TRY(hipMemsetAsync(w->step_zero.p, 0, w->step_zero_full_bytes, w->stream));
+        w->step_zero_full_bytes = b_bytes + c_bytes + kCountersExtentResetBytes;  // not the sticky word behind it
+        PHYS_HIP_TRY(hipMemsetAsync(w->step_zero.p, 0, b_bytes + c_bytes + sizeof(StepCounters), w->stream));  // sticky word too
     }
     PHYS_HIP_TRY(w->bucket_of.resize(n));
     PHYS_HIP_TRY(w->bucket_cursor.resize(n));  // rank of each body inside its bucket
@@ -566,9 +566,14 @@ int32_t collision_alloc(phys_world* w) {
             w->color_epoch = 0;
         }
         PHYS_HIP_TRY(w->color_block_hist.resize((size_t)kMaxColors * 512));
-        PHYS_HIP_TRY(w->row_hdr.resize(4 * M)); PHYS_HIP_TRY(w->row_n.resize(4 * M));
-        PHYS_HIP_TRY(w->row_pt.resize(32 * M)); PHYS_HIP_TRY(w->row_tb.resize(8 * M));
-        PHYS_HIP_TRY(w->row_acc.resize(16 * M));
+        w->row_hdr.free(); w->row_n.free(); w->row_tb.free(); w->row_pt.free(); w->row_acc.free();
+        w->row_all.free();
+        PHYS_HIP_TRY(w->row_all.resize(64 * M));  // 16 planes x M x float4
+        w->row_hdr.point_at(reinterpret_cast<uint32_t*>(w->row_all.p), 4 * M);
+        w->row_n.point_at(w->row_all.p + 4 * M, 4 * M);
+        w->row_tb.point_at(w->row_all.p + 8 * M, 8 * M);
+        w->row_pt.point_at(w->row_all.p + 16 * M, 32 * M);
+        w->row_acc.point_at(w->row_all.p + 48 * M, 16 * M);
         w->flow_vel.free();
         // the dataflow solver addresses row_acc / flow_vel through 32-bit buffer offsets
         if (!(w->cfg.flags & PHYS_FLAG_SOLVER_PER_COLOR) && 64 * M < 0xFFFFFFFFull && 32 * n < 0xFFFFFFFFull) {

@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256) void k_halo_pack(uint32_t n, const float* __re
             r.pad = 0;
             out[slot] = r;
         } else {
-            atomicOr(&ctr->overflow, 8u);
+            flag_overflow(ctr, 8u);
         }
     }
 }
@@ -86,7 +86,7 @@ __device__ __forceinline__ void emit_cross_pairs(bool hit, uint32_t j, uint32_t 
         if (hit) {
             const uint64_t slot = (uint64_t)base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
             if (slot < cap) { cross_pairs[2 * slot] = j; cross_pairs[2 * slot + 1] = rgid; }
-            else atomicOr(&ctr->overflow, 8u);
+            else flag_overflow(ctr, 8u);
         }
     }
 }

@@ -92,7 +92,7 @@ __global__ __launch_bounds__(kNpThreads) void k_narrowphase(
                 bb = atomicAdd(&ctr->n_manifolds, t);
                 const uint64_t room = (uint64_t)bb < max_manifolds ? max_manifolds - bb : 0;
                 const uint32_t stored = (uint64_t)t <= room ? t : (uint32_t)room;
-                if (stored != t) atomicOr(&ctr->overflow, 2u);
+                if (stored != t) flag_overflow(ctr, 2u);
                 atomicAdd(&ctr->n_contacts, tp);
                 if (tg) atomicAdd(&ctr->n_ground_manifolds, tg);
             }
@@ -125,8 +125,13 @@ __global__ __launch_bounds__(kNpThreads) void k_narrowphase(
                 }
                 man_color[slot] = col;
                 if (col != kUncolored) {
-                    atomicOr(&used[a], 1ull << col);  // order-independent
-                    if (b != PHYS_GROUND_ID) atomicOr(&used[b], 1ull << col);
+                    // order-independent. A kept colour that is ALREADY in use at one of the bodies means the previous
+                    // colouring was not proper (it saturated at PHYS_MAX_COLORS): two rows of one colour on one body
+                    // would race in the solver, so the step is flagged like any other colour overflow (no solve)
+                    const unsigned long long bit = 1ull << col;
+                    bool clash = (atomicOr(&used[a], bit) & bit) != 0ull;
+                    if (b != PHYS_GROUND_ID) clash = ((atomicOr(&used[b], bit) & bit) != 0ull) || clash;
+                    if (clash) flag_overflow(ctr, 4u);
                 } else {
                     uncolored = true;
                     // round 0 of the colouring: per-body maximum priority (order-independent u64 max)
@@ -203,7 +208,7 @@ __device__ __forceinline__ uint32_t color_round_lanes(uint32_t first, uint32_t s
             mask |= mb;
             uint32_t c = 0;
             while (c < (uint32_t)(PHYS_MAX_COLORS - 1) && ((mask >> c) & 1ull)) ++c;
-            if (((mask >> c) & 1ull)) atomicOr(&ctr->overflow, 4u);  // more than PHYS_MAX_COLORS at one body
+            if (((mask >> c) & 1ull)) flag_overflow(ctr, 4u);  // more than PHYS_MAX_COLORS at one body
             // the winner is the only manifold touching a or b that colours this round
             if (BYPASS_L1) {
                 __hip_atomic_store(&used[a], ma | (1ull << c), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -625,7 +630,10 @@ void launch_coloring(phys_world* w) {
         // one workgroup does the whole stage, snapshot of the counters included
         StepCounters* slot = snapshot_acquire(w);
         StepCounters* d_slot = nullptr;
-        if (slot && hipHostGetDevicePointer((void**)&d_slot, slot, 0) != hipSuccess) d_slot = nullptr;
+        if (slot && hipHostGetDevicePointer((void**)&d_slot, slot, 0) != hipSuccess) {
+            d_slot = nullptr;
+            (void)hipGetLastError();  // an answer handled here (the copy path takes over), not an error to leave behind
+        }
         { PHYS_PROF(w, PHYS_STAGE_COLOR);
           hipLaunchKernelGGL(k_color_small, dim3(1), dim3(kColorThreads), 0, s, w->max_manifolds, w->man_a.p, w->man_b.p,
                              w->man_color.p, w->man_prio.p, w->color_state.p, (uint64_t)n, w->row_src.p, w->counters.p, d_slot); }

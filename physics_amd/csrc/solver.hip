@@ -50,6 +50,7 @@ __device__ __forceinline__ m33 ld_inertia<true>(const float* __restrict__ p, uin
 }
 
 struct RowArrays {
+    float4* all;  // the 16 planes in one piece: plane p of row d = all[p * cap + d] (0 hdr, 1 n, 2-3 tb, 4-11 pt, 12-15 acc)
     uint4* hdr;
     float4* n;
     float4* pt;
@@ -58,6 +59,7 @@ struct RowArrays {
     uint64_t cap;
 };
 
+template <bool DIAG>
 __global__ __launch_bounds__(256) void k_rows_build(const StepCounters* __restrict__ ctr, RowArrays rows, solve_params_t sp,
                                                     const uint32_t* __restrict__ row_src,
                                                     const uint32_t* __restrict__ man_a, const uint32_t* __restrict__ man_b,
@@ -65,7 +67,7 @@ __global__ __launch_bounds__(256) void k_rows_build(const StepCounters* __restri
                                                     const float* __restrict__ man_normal,
                                                     const float* __restrict__ man_points, const float* __restrict__ pos,
                                                     const float* __restrict__ vel,
-                                                    const float* __restrict__ inv_inertia,
+                                                    const float* __restrict__ inv_inertia, uint32_t inertia_stride,
                                                     const uint32_t* __restrict__ man_color,
                                                     const unsigned long long* __restrict__ used,
                                                     int flow /* 1: k_solve_flow runs this step (tickets, no zeroed impulses) */,
@@ -73,7 +75,9 @@ __global__ __launch_bounds__(256) void k_rows_build(const StepCounters* __restri
     {
         // colour table for the next update's narrow phase: built even when the solve is skipped, or the update after
         // an overflow would keep colours from a table two updates old
-        const uint32_t raw = ctr->n_manifolds;
+        // ... but an improper colouring (colour overflow, bit 2) must not be inherited: the table is then built EMPTY
+        // and the next update colours everything from scratch
+        const uint32_t raw = (ctr->overflow & 4u) ? 0u : ctr->n_manifolds;
         if (table.keys) color_table_update(table, (uint64_t)raw < rows.cap ? raw : (uint32_t)rows.cap);
     }
     if (ctr->overflow) return;  // never solve a truncated set; phys_sync / phys_get_stats report it
@@ -93,13 +97,15 @@ __global__ __launch_bounds__(256) void k_rows_build(const StepCounters* __restri
             g.depth[k] = p.w;
         }
         const int has_b = b != PHYS_GROUND_ID;
-        const m33 IA = ld_m33(inv_inertia, a);
+        // DIAG: 16 bytes per body instead of 36 (and none at all when every body shares one tensor: stride 0);
+        // the zero off-diagonals are put back, so solver_prep's arithmetic is the general path's
+        const m33 IA = ld_inertia<DIAG>(inv_inertia, a * inertia_stride);
         m33 IB;
 #pragma unroll
         for (int k = 0; k < 9; ++k) IB.m[k] = 0.0f;
         float imb = 0.0f;
         v3 xB = v3_make(0.0f, 0.0f, 0.0f);
-        if (has_b) { IB = ld_m33(inv_inertia, b); imb = vel[8 * (size_t)b + 3]; xB = ld3(pos, b); }
+        if (has_b) { IB = ld_inertia<DIAG>(inv_inertia, b * inertia_stride); imb = vel[8 * (size_t)b + 3]; xB = ld3(pos, b); }
         solver_manifold_t sm;
         solver_prep(&g, has_b, ld3(pos, a), xB, vel[8 * (size_t)a + 3], &IA, imb, &IB, &sp, &sm);
         uint32_t ticket = 0;
@@ -140,9 +146,22 @@ struct RowRegs {
 
 // everything of a row that does NOT depend on body velocities. ACC: also the accumulated impulses (plain loads;
 // k_solve_flow receives them as tagged granules instead)
-template <bool ACC>
+// EAGER: every plane of the row is fetched at once, whatever the point count turns out to be (planes beyond it hold
+// stale but readable data that is then ignored): no load waits for the header. For the per-colour kernel of large
+// scenes, where a launch is one wave per SIMD and a second dependent round trip to memory is ~1.5 us of every launch.
+template <bool ACC, bool EAGER = false>
 __device__ __forceinline__ void load_row(RowRegs& R, uint32_t d, const RowArrays& rows) {
     const uint64_t cap = rows.cap;
+    float4 e_p0[4], e_p1[4], e_acc[4], e_t23;
+    if (EAGER) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            e_p0[k] = rows.pt[(size_t)(2 * k) * cap + d];
+            e_p1[k] = rows.pt[(size_t)(2 * k + 1) * cap + d];
+            if (ACC) e_acc[k] = rows.acc[(size_t)k * cap + d];
+        }
+        e_t23 = rows.tb[cap + d];
+    }
     const uint4 h = rows.hdr[d];
     R.a = h.x; R.b = h.y; R.ticket = h.w;
     solver_manifold_t& sm = R.sm;
@@ -153,20 +172,20 @@ __device__ __forceinline__ void load_row(RowRegs& R, uint32_t d, const RowArrays
     tangent_basis(sm.n, &sm.t1, &sm.t2);  // same inputs as solver_prep => same bits as the basis used there
     const float4 t01 = rows.tb[d];
     float4 t23 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    if (sm.count > 2) t23 = rows.tb[cap + d];
+    if (sm.count > 2) t23 = EAGER ? e_t23 : rows.tb[cap + d];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         contact_row_t& c = sm.row[k];
         if (k < sm.count) {
-            const float4 p0 = rows.pt[(size_t)(2 * k) * cap + d];
-            const float4 p1 = rows.pt[(size_t)(2 * k + 1) * cap + d];
+            const float4 p0 = EAGER ? e_p0[k] : rows.pt[(size_t)(2 * k) * cap + d];
+            const float4 p1 = EAGER ? e_p1[k] : rows.pt[(size_t)(2 * k + 1) * cap + d];
             c.rA = v3_make(p0.x, p0.y, p0.z); c.normal_mass = p0.w;
             c.rB = v3_make(p1.x, p1.y, p1.z); c.tangent_mass[0] = p1.w;
             const float4 t = k < 2 ? t01 : t23;
             c.tangent_mass[1] = (k & 1) ? t.z : t.x;
             c.bias = (k & 1) ? t.w : t.y;
             if (ACC) {
-                const float4 acc = rows.acc[(size_t)k * cap + d];
+                const float4 acc = EAGER ? e_acc[k] : rows.acc[(size_t)k * cap + d];
                 c.pn = acc.x; c.pt[0] = acc.y; c.pt[1] = acc.z;
             } else {
                 c.pn = 0.0f; c.pt[0] = 0.0f; c.pt[1] = 0.0f;
@@ -180,13 +199,13 @@ __device__ __forceinline__ void load_row(RowRegs& R, uint32_t d, const RowArrays
 }
 
 // gather the two bodies, solve_manifold, write velocities and accumulated impulses back
-template <bool DIAG>
+template <bool DIAG, bool EAGER = false>
 __device__ __forceinline__ void solve_row(uint32_t d, const RowArrays& rows, float friction,
                                           const float* __restrict__ inv_inertia,
                                           uint32_t inertia_stride /* 0: one tensor shared by every body */,
                                           float* __restrict__ vel) {
     RowRegs R;
-    load_row<true>(R, d, rows);
+    load_row<true, EAGER>(R, d, rows);
     solver_manifold_t& sm = R.sm;
     const uint32_t a = R.a, b = R.b;
     const m33 IA = ld_inertia<DIAG>(inv_inertia, a * inertia_stride);
@@ -220,7 +239,7 @@ __global__ __launch_bounds__(256) void k_solve_color(const StepCounters* __restr
     if (ctr->overflow) return;
     const uint32_t start = ctr->color_start[col], end = ctr->color_start[col + 1];
     for (uint32_t d = start + blockIdx.x * blockDim.x + threadIdx.x; d < end; d += gridDim.x * blockDim.x)
-        solve_row<DIAG>(d, rows, friction, inv_inertia, inertia_stride, vel);
+        solve_row<DIAG, true>(d, rows, friction, inv_inertia, inertia_stride, vel);
 }
 
 // The colour classes [first, n_colours) of one iteration in ONE launch of ONE workgroup: colours in
@@ -420,7 +439,7 @@ __global__ __launch_bounds__(256) void k_solve_flow(StepCounters* __restrict__ c
                 const bool dead = (wall_clock64() - t_start > timeout_ticks) ||
                                   (__hip_atomic_load(&ctr->overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 16u);
                 if (dead) {  // wave-uniform: both inputs are
-                    if ((threadIdx.x & 63u) == 0u) atomicOr(&ctr->overflow, 16u);
+                    if ((threadIdx.x & 63u) == 0u) flag_overflow(ctr, 16u);
                     done = true;
                 }
             }
@@ -630,11 +649,171 @@ __global__ __launch_bounds__(256) void k_solve_flow_quad(StepCounters* __restric
                 const bool dead = (wall_clock64() - t_start > timeout_ticks) ||
                                   (__hip_atomic_load(&ctr->overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 16u);
                 if (dead) {
-                    if ((threadIdx.x & 63u) == 0u) atomicOr(&ctr->overflow, 16u);
+                    if ((threadIdx.x & 63u) == 0u) flag_overflow(ctr, 16u);
                     done = true;
                 }
             }
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// One colour of one iteration with FOUR LANES PER MANIFOLD and the rows staged through LDS: the per-colour
+// kernel for scenes whose colour classes fill the chip (above kFlowMaxManifolds). k_solve_color runs one lane
+// per manifold: a colour of 60-70k manifolds is then ~270 workgroups = one wave per SIMD, each lane a chain of
+// header load -> ~20 dependent dwordx4 loads -> ~1200 VALU instructions -> stores with nothing to overlap it
+// (17 us per launch for 26-33 MB, 19-24 % of the HBM rate). Here
+//   * a workgroup owns 64 consecutive rows; every 16-byte element of the 16 row planes of those rows is loaded
+//     ONCE (wave w fetches planes 4w..4w+3, 1 KiB contiguous per instruction, all issued before anything
+//     else: no load depends on the header any more) and parked in LDS (16 KiB);
+//   * lane q of a quad owns one of {vA, wA, vB, wB} exactly as in k_solve_flow_quad (same arithmetic, same
+//     DPP order of the partial sums => same bits): a third of the VALU chain per lane, four times the waves
+//     to overlap memory with arithmetic, and a gather of ONE 16-byte half record per lane.
+// Rows of one colour share no body, so the plain loads / stores of `vel` need no ordering inside a launch.
+constexpr int kQuadRowsPerGroup = 64;
+template <bool DIAG>
+__global__ __launch_bounds__(256) void k_solve_color_quad(StepCounters* ctr, uint32_t col, RowArrays rows,
+                                                          float friction, const float* __restrict__ inv_inertia,
+                                                          uint32_t inertia_stride, float* __restrict__ vel, uint32_t n_bodies) {
+    __shared__ float4 s_rows[16][kQuadRowsPerGroup];  // [plane][row of this workgroup]
+    if (ctr->overflow) return;
+    const uint32_t start = ctr->color_start[col], end = ctr->color_start[col + 1];
+    const uint32_t cap = (uint32_t)rows.cap;
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t q = threadIdx.x & 3u, r = threadIdx.x >> 2;  // q: 0 vA, 1 wA, 2 vB, 3 wB
+    const bool side_a = q < 2u, angular = (q & 1u) != 0u;
+    const v3 zero = v3_make(0.0f, 0.0f, 0.0f);
+    // the four planes this wave stages: 4 * wave + j of the ONE row allocation (0 hdr, 1 n, 2-3 tb, 4-11 pt, 12-15 acc).
+    // Plain arithmetic on purpose: written as `if (wave == 0) {pointers..} else if ..` over the five arrays, hipcc
+    // (ROCm 7.2) lost one case of the pointer selection (wave 3 staged from a null pointer: memory access fault)
+    const float4* pl = rows.all + (size_t)(4u * wave) * cap;
+    for (uint32_t base = start + blockIdx.x * kQuadRowsPerGroup; base < end; base += gridDim.x * kQuadRowsPerGroup) {
+        {
+            // rows beyond `end` belong to later colours (read only, never used); beyond the arrays: clamp
+            uint32_t e = base + lane;
+            e = e < cap ? e : cap - 1u;
+            const float4 t0 = pl[e], t1 = pl[(size_t)cap + e], t2 = pl[2 * (size_t)cap + e], t3 = pl[3 * (size_t)cap + e];
+            s_rows[4 * wave + 0][lane] = t0; s_rows[4 * wave + 1][lane] = t1;
+            s_rows[4 * wave + 2][lane] = t2; s_rows[4 * wave + 3][lane] = t3;
+        }
+        __syncthreads();
+        const uint32_t d = base + r;
+        const bool live = d < end;  // the same for the four lanes of a quad
+        v3 x = zero, Jv[4][3], Rs[4][3];
+        float nm[4], tm0[4], tm1[4], bias[4], pn[4], pt0[4], pt1[4];
+        float keep_w = 0.0f;
+        uint32_t body = 0, count = 0;
+        bool has_body = false;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            nm[k] = 0.0f; tm0[k] = 0.0f; tm1[k] = 0.0f; bias[k] = 0.0f; pn[k] = 0.0f; pt0[k] = 0.0f; pt1[k] = 0.0f;
+#pragma unroll
+            for (int t = 0; t < 3; ++t) { Jv[k][t] = zero; Rs[k][t] = zero; }
+        }
+        if (live) {
+            const float4 hraw = s_rows[0][r];
+            const uint32_t ha = __float_as_uint(hraw.x), hb = __float_as_uint(hraw.y);
+            count = __float_as_uint(hraw.z);
+            const bool has_b = hb != PHYS_GROUND_ID;
+            body = side_a ? ha : hb;
+            has_body = side_a || has_b;
+            // a row header that names no body of this world must never become an address (a faulting kernel can
+            // take the whole node down): flag the step (bit 5) and skip the row
+            if (count > 4u || (has_body && body >= n_bodies)) {
+                flag_overflow(ctr, 32u);
+                ctr->debug[0] = d; ctr->debug[1] = ha; ctr->debug[2] = hb; ctr->debug[3] = count;
+                ctr->debug[4] = start; ctr->debug[5] = end; ctr->debug[6] = col; ctr->debug[7] = base;
+                count = 0; has_body = false;
+            }
+            m33 I;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) I.m[k] = 0.0f;
+            float inv_m = 0.0f;
+            if (has_body) {
+                // this lane's half of the velocity record: {v, 1/m} or {w, m}
+                const float4 h0 = reinterpret_cast<const float4*>(vel)[2 * (size_t)body + (angular ? 1 : 0)];
+                x = v3_make(h0.x, h0.y, h0.z);
+                keep_w = h0.w;
+                if (angular) I = ld_inertia<DIAG>(inv_inertia, body * inertia_stride); else inv_m = h0.w;
+            }
+            const float4 nn = s_rows[1][r];
+            v3 dir[3];
+            dir[2] = v3_make(nn.x, nn.y, nn.z);
+            tangent_basis(dir[2], &dir[0], &dir[1]);
+            const float4 t01 = s_rows[2][r];
+            float4 t23 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (count > 2) t23 = s_rows[3][r];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (k < (int)count) {
+                    const float4 p0 = s_rows[4 + 2 * k][r];      // rA, normal mass
+                    const float4 p1 = s_rows[4 + 2 * k + 1][r];  // rB, tangent mass 0
+                    const float4 ac = s_rows[12 + k][r];         // accumulated impulses of point k
+                    nm[k] = p0.w; tm0[k] = p1.w;
+                    const float4 tt = k < 2 ? t01 : t23;
+                    tm1[k] = (k & 1) ? tt.z : tt.x;
+                    bias[k] = (k & 1) ? tt.w : tt.y;
+                    pn[k] = ac.x; pt0[k] = ac.y; pt1[k] = ac.z;
+                    const v3 rr = side_a ? v3_make(p0.x, p0.y, p0.z) : v3_make(p1.x, p1.y, p1.z);
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) {
+                        if (has_body) {
+                            // solver_jacobians: lA = dir * invM; aA = r x dir, mA = I aA; the A side is subtracted by
+                            // the spec, so its response is stored negated (exact)
+                            v3 jv, rs;
+                            if (angular) { jv = v3_cross(rr, dir[t]); rs = m33_mul_v3(&I, jv); }
+                            else { jv = dir[t]; rs = v3_scale(dir[t], inv_m); }
+                            Jv[k][t] = jv;
+                            Rs[k][t] = side_a ? v3_neg(rs) : rs;
+                        }
+                    }
+                }
+            }
+            if (!has_body) x = zero;
+        }
+        // every lane takes part in the DPP exchanges (dead quads carry zeros)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (k < (int)count) {
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    // row_velocity: (dir.vB + aB.wB) - (dir.vA + aA.wA), the two sums made inside each pair
+                    const float part = v3_dot(Jv[k][t], x);
+                    const float mine = part + quad_perm<kQuadXor1>(part);
+                    const float other = quad_perm<kQuadXor2>(mine);
+                    const float vrel = side_a ? other - mine : mine - other;
+                    float lambda;
+                    if (t < 2) {  // solve_row_dir, friction
+                        const float mass = t == 0 ? tm0[k] : tm1[k];
+                        float& acc = t == 0 ? pt0[k] : pt1[k];
+                        lambda = -mass * vrel;
+                        const float maxf = friction * pn[k];
+                        const float old = acc;
+                        const float np = det_maxf(-maxf, det_minf(old + lambda, maxf));
+                        lambda = np - old;
+                        acc = np;
+                    } else {      // normal
+                        lambda = nm[k] * (bias[k] - vrel);
+                        const float old = pn[k];
+                        const float np = det_maxf(old + lambda, 0.0f);
+                        lambda = np - old;
+                        pn[k] = np;
+                    }
+                    x = v3_add(x, v3_scale(Rs[k][t], lambda));  // row_apply
+                }
+            }
+        }
+        if (live) {
+            if (has_body)
+                reinterpret_cast<float4*>(vel)[2 * (size_t)body + (angular ? 1 : 0)] = make_float4(x.x, x.y, x.z, keep_w);
+            if (q < count) {
+                const float4 mine = q == 0 ? make_float4(pn[0], pt0[0], pt1[0], 0.0f)
+                                  : q == 1 ? make_float4(pn[1], pt0[1], pt1[1], 0.0f)
+                                  : q == 2 ? make_float4(pn[2], pt0[2], pt1[2], 0.0f) : make_float4(pn[3], pt0[3], pt1[3], 0.0f);
+                rows.acc[(size_t)q * cap + d] = mine;
+            }
+        }
+        __syncthreads();  // the LDS tile is restaged by the next trip
     }
 }
 
@@ -657,6 +836,7 @@ void launch_solver(phys_world* w, float dt) {
     const float* inertia = diag ? w->inv_inertia_diag.p : w->inv_inertia.p;
     const uint32_t stride = diag && w->uniform_inertia ? 0u : 1u;
     RowArrays rows;
+    rows.all = reinterpret_cast<float4*>(w->row_all.p);
     rows.hdr = reinterpret_cast<uint4*>(w->row_hdr.p);
     rows.n = reinterpret_cast<float4*>(w->row_n.p);
     rows.pt = reinterpret_cast<float4*>(w->row_pt.p);
@@ -675,7 +855,10 @@ void launch_solver(phys_world* w, float dt) {
     // beyond that the per-colour launches stream better. Both give the same bits, so the choice may change
     // from step to step.
     // (tickets are 16-bit: iterations x 64 colours must stay below 65536)
-    const bool flow = w->flow_vel.p && h.valid && m_hint <= kFlowMaxManifolds && w->cfg.solver_iterations > 0 &&
+    // PHYS_DEBUG_FLOW_MAX=<manifolds>: move the dataflow / per-colour crossover (measurements only; same bits either way)
+    static const char* flow_max_env = getenv("PHYS_DEBUG_FLOW_MAX");
+    const uint64_t flow_max = flow_max_env ? strtoull(flow_max_env, nullptr, 10) : kFlowMaxManifolds;
+    const bool flow = w->flow_vel.p && h.valid && m_hint <= flow_max && w->cfg.solver_iterations > 0 &&
                       w->cfg.solver_iterations < 1000;
     // fault injection for tests/test_gpu_full_size.py: one row gets a ticket nobody will ever publish, so the bounded
     // spin of the dataflow kernels must give up, flag the step (overflow bit 4) and let the launch end
@@ -693,9 +876,15 @@ void launch_solver(phys_world* w, float dt) {
         table.man_a = w->man_a.p; table.man_b = w->man_b.p; table.man_color = w->man_color.p; table.man_prio = w->man_prio.p;
         w->ctab_job_pending = false;
     }
-    { PHYS_PROF(w, PHYS_STAGE_ROWS); hipLaunchKernelGGL(k_rows_build, grid_for_count(m_hint), tb, 0, s, w->counters.p, rows, sp, w->row_src.p, w->man_a.p, w->man_b.p, w->man_count.p,
-                       w->man_normal.p, w->man_points.p, w->pos.p, w->vel.p, w->inv_inertia.p, w->man_color.p,
-                       w->color_state.p, flow ? (stall ? 2 : 1) : 0, table); }
+    { PHYS_PROF(w, PHYS_STAGE_ROWS);
+      if (diag)
+          hipLaunchKernelGGL(k_rows_build<true>, grid_for_count(m_hint), tb, 0, s, w->counters.p, rows, sp, w->row_src.p, w->man_a.p, w->man_b.p, w->man_count.p,
+                             w->man_normal.p, w->man_points.p, w->pos.p, w->vel.p, inertia, stride, w->man_color.p,
+                             w->color_state.p, flow ? (stall ? 2 : 1) : 0, table);
+      else
+          hipLaunchKernelGGL(k_rows_build<false>, grid_for_count(m_hint), tb, 0, s, w->counters.p, rows, sp, w->row_src.p, w->man_a.p, w->man_b.p, w->man_count.p,
+                             w->man_normal.p, w->man_points.p, w->pos.p, w->vel.p, inertia, stride, w->man_color.p,
+                             w->color_state.p, flow ? (stall ? 2 : 1) : 0, table); }
     if (flow) {
         if (++w->flow_epoch > 0xFFFFu) {  // tags would repeat: forget every old one
             (void)hipMemsetAsync(w->flow_vel.p, 0, 8 * w->n * sizeof(float), s);
@@ -725,9 +914,31 @@ void launch_solver(phys_world* w, float dt) {
         while (big > 0 && h.color_count[big - 1] <= kTailMax) --big;
         if (h.n_colors - big < 2) big = h.n_colors;  // a tail of one colour is just a slower launch
     }
+    // PHYS_DEBUG_COLOR_KERNEL=lane: the one-lane-per-manifold kernel for every colour (A/B measurements, parity tests)
+    static const char* color_kernel_env = getenv("PHYS_DEBUG_COLOR_KERNEL");
+    // four lanes per manifold while a colour is too small to fill the chip with one lane per manifold (measured
+    // crossover ~30k rows: 15k rows 10.2 vs 11.9 us per launch, 53k rows 18.3 vs 16.7, 85k rows 21.5 vs 18.7)
+    constexpr uint32_t kQuadColorMaxRows = 32768;
+    const int color_kernel_mode = !color_kernel_env ? 0 : (color_kernel_env[0] == 'l' ? 1 : 2);  // 0 auto, 1 lane, 2 quad
+    auto grid_for_quads = [&](uint64_t count) {
+        uint64_t b = (count * 5 / 4 + kQuadRowsPerGroup - 1) / kQuadRowsPerGroup + 1;
+        const uint64_t hi = (cap + kQuadRowsPerGroup - 1) / kQuadRowsPerGroup;
+        if (b > hi) b = hi;
+        if (b > 16384) b = 16384;
+        return dim3((unsigned)(b ? b : 1));
+    };
     for (uint32_t it = 0; it < w->cfg.solver_iterations; ++it) {
         for (uint32_t col = 0; col < big; ++col) {
             PHYS_PROF(w, PHYS_STAGE_SOLVE);
+            if (color_kernel_mode == 2 || (color_kernel_mode == 0 && h.color_count[col] <= kQuadColorMaxRows)) {
+                if (diag)
+                    hipLaunchKernelGGL(k_solve_color_quad<true>, grid_for_quads(h.color_count[col]), tb, 0, s, w->counters.p, col, rows,
+                                       sp.friction, inertia, stride, w->vel.p, (uint32_t)w->n);
+                else
+                    hipLaunchKernelGGL(k_solve_color_quad<false>, grid_for_quads(h.color_count[col]), tb, 0, s, w->counters.p, col, rows,
+                                       sp.friction, inertia, stride, w->vel.p, (uint32_t)w->n);
+                continue;
+            }
             if (diag)
                 hipLaunchKernelGGL(k_solve_color<true>, grid_for_count(h.color_count[col]), tb, 0, s, w->counters.p, col, rows,
                                    sp.friction, inertia, stride, w->vel.p);

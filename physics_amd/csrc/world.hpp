@@ -62,7 +62,7 @@ struct StepCounters {
     uint32_t n_uncolored;    // manifolds still uncoloured (colouring loop)
     uint32_t n_colors;       // colours in use
     uint32_t color_rounds;
-    uint32_t overflow;       // bit 0 pairs, bit 1 manifolds, bit 2 colours, bit 3 cross pairs, bit 4 solver hand-off timeout
+    uint32_t overflow;       // bit 0 pairs, bit 1 manifolds, bit 2 colours, bit 3 cross pairs, bit 4 solver hand-off timeout, bit 5 corrupt solver row refused
     uint32_t n_halo;         // halo records packed
     uint32_t n_cross_pairs;
     uint32_t n_ground_manifolds;
@@ -75,8 +75,21 @@ struct StepCounters {
     // fattened-AABB edge (float bits; positive floats order as uints), re-derived from zero every 32 steps.
     // Any upper bound is a valid grid cell size: the pair SET does not depend on it.
     alignas(16) uint32_t max_extent_bits;
+    // Every overflow bit ever raised since the host last looked (phys_sync reports and clears it). `overflow` above
+    // is per step - the first kernel of the next step zeroes it - so a capacity miss or a hand-off timeout in an
+    // EARLY step of a phys_update_n batch would otherwise be gone by the time the host synchronises. Zeroed by
+    // neither the per-step reset nor the extent restart (both stop short of it).
+    uint32_t sticky_overflow;
+    uint32_t debug[8];  // what a kernel that refused a corrupt row saw (overflow bit 5); never read by device code
 };
 constexpr size_t kCountersStepResetBytes = offsetof(StepCounters, max_extent_bits);
+constexpr size_t kCountersExtentResetBytes = offsetof(StepCounters, sticky_overflow);
+
+// raise overflow bits: this step's word (the solver kernels of the step look at it) and the sticky one
+__device__ __forceinline__ void flag_overflow(StepCounters* ctr, uint32_t bits) {
+    atomicOr(&ctr->overflow, bits);
+    atomicOr(&ctr->sticky_overflow, bits);
+}
 
 // per-stage device timing with HIP events on the world's stream (phys_profile_enable)
 struct Profiler {
@@ -206,6 +219,9 @@ struct phys_world {
     phys::DevBuf<unsigned long long> color_state;  // 4n: used masks | three rotating per-body priority buffers
     // solver rows, colour-major, plane-major arrays of 16-byte elements (layout: solver.hip)
     phys::DevBuf<uint32_t> row_src;  // row -> manifold (the colour sort)
+    // ONE allocation of 16 planes of cap float4 each; the arrays below are windows into it (plane 0 hdr, 1 n, 2-3 tb,
+    // 4-11 pt, 12-15 acc), so a kernel can address plane p of row d as all[p * cap + d] without choosing a pointer
+    phys::DevBuf<float> row_all;
     phys::DevBuf<uint32_t> row_hdr;  // 4 per row: body a, body b, point count, update tickets
     phys::DevBuf<float> row_n;       // 4 per row
     phys::DevBuf<float> row_pt;      // 8 planes of float4
@@ -229,6 +245,7 @@ struct phys_world {
     bool snap_tag_full = false;
     uint32_t snap_next = 0;
     phys::Profiler prof;
+    uint32_t host_sticky_overflow = 0;  // overflow bits seen in counter snapshots (poll_snapshots), until phys_sync
     phys_stats stats{};
     // pinned host mirror of the counters for read-back
     phys::StepCounters* h_counters = nullptr;

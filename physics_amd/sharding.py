@@ -85,6 +85,7 @@ class HaloExchange:
 
     def attach(self, world, x_lo, x_hi, global_ids, half_extent, margin):
         self.x_lo, self.x_hi = float(x_lo), float(x_hi)
+        self._ext_stream = None  # a new world launches on a new stream
         world.set_global_ids(global_ids)
         # reach must cover the largest AABB of ANY rank: one all-reduce at set-up time
         r = self.torch.tensor([static_reach(half_extent, margin)], dtype=self.torch.float64, device=self.device)

@@ -27,16 +27,10 @@ def _gpu_available():
         return False
 
 
-@pytest.fixture(scope="session", autouse=True)
-def _torch_gpu_first():
-    """On a GPU box, bring PyTorch's HIP context up before libphysics_hip touches the device: tests that open
-    torch streams / RCCL groups later then never depend on which other tests ran before them (initialising torch
-    after the library had been used failed with hipErrorNoDevice for one particular subset of tests)."""
-    if _gpu_available():
-        import torch
-        torch.cuda.init()
-        torch.zeros(1, device="cuda")
-    yield
+# (Round 1 had an autouse fixture here that initialised PyTorch before the library touched the GPU. The failure it
+# papered over - torch.cuda.Stream() raising hipErrorNoDevice after the library had been used - was two ROCm runtimes in
+# one process (PyTorch bundles its own libamdhip64.so); physics_amd._abi.share_rocm_runtime_with_torch() now makes both
+# share one whichever loads first, and tests/test_gpu_runtime_order.py runs the failing order in a fresh process.)
 
 
 @pytest.fixture(scope="session")

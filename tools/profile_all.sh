@@ -1,16 +1,23 @@
 #!/bin/bash
-# Round profile collection: rocprofv3 kernel-trace stats and the two PMC passes (separate runs) for the bench
-# workload (c2) and the 1M target scene. Outputs under gpurun_out/; tools/kstats.py and profiles/collect_pmc.py
-# turn them into the files kept under profiles/.
+# Round profile collection on the GPU box: for every workload the SAME command three times under rocprofv3 -
+# kernel trace, then the two PMC passes (separate runs: the guide's rule, and gpurun refuses --pmc next to tracing
+# domains other than the kernel trace). tools/profile_window.py then cuts the timed window out of each and writes
+# profiles/r2_<wl>_window.json (run it here, on the merged gpurun_out/).
+#   tools/profile_all.sh c5 t1m c3 c2
 set -e
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-for wl in c2 t1m; do
-  # the same commands bench.py runs by default: C2 with its default 1000 timed steps, the 1M scene with 60
-  args="--workload $wl --no-cpu-baseline --no-extra"; [ "$wl" = "t1m" ] && args="$args --steps 60"
-  timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$wl -- python3 bench.py $args > gpurun_out/prof_$wl.log 2>&1
+out=gpurun_out/prof_r2
+mkdir -p $out
+for wl in "$@"; do
+  args="--workload $wl --warmup 5 --steps 20 --profile-window"
+  python3 bench.py $args > $out/window_$wl.json 2> $out/window_$wl.err
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_$wl -- python3 bench.py $args > $out/trace_$wl.log 2>&1
   echo "trace $wl done"
   for c in FETCH_SIZE WRITE_SIZE; do
-    timeout -k 10 600 rocprofv3 --pmc $c --output-format csv -d gpurun_out/pmc_${wl}_$c -- python3 bench.py $args > gpurun_out/pmc_${wl}_$c.log 2>&1
+    timeout -k 10 400 rocprofv3 --pmc $c --output-format csv -d $out/pmc_${wl}_$c -- python3 bench.py $args > $out/pmc_${wl}_$c.log 2>&1
     echo "pmc $wl $c done"
   done
+  # keep the merged output small: the per-dispatch tables of the window are all that is needed
+  find $out -name "*agent_info.csv" -delete
 done
+du -sh $out
