@@ -13,8 +13,9 @@ very same K steps of the same trajectory (the step is deterministic: bit-identic
 MEDIAN repetition; min / max are reported beside it. Each timed region is bracketed by barrier +
 torch.cuda.synchronize() + phys_sync on both sides; with several ranks the time of a repetition is the MAX over ranks.
 
-N > 1 (`--gpus N`): weak scaling; every rank owns one workload-shaped slab placed side by side along x, the broad
-phase exchanges boundary AABBs with one RCCL all-gather per step (one process per GPU). Started without a
+N > 1 (`--gpus N`): weak scaling; every rank owns one workload-shaped slab placed side by side along x and, once per
+step, all-gathers the state of its boundary bodies over RCCL (behind the C ABI: phys_halo_exchange; one process per
+GPU): the neighbours' boundary bodies take part in the rank's broad phase, narrow phase and solver as kinematic ghosts. Started without a
 launcher (no WORLD_SIZE in the environment) this script starts the N ranks itself, BEFORE anything touches the GPU.
 
 Prints ONE JSON line (rank 0). `roofline` describes the dominant kernel of the timed window, timed live with HIP
@@ -153,7 +154,11 @@ class Rig:
             return
         if self.halo is None:
             world.update_n(DT_NANOS, steps)
-        else:
+        elif self.halo.before_update:  # ghost bodies: exchanged first, collided with inside the update
+            for _ in range(steps):
+                self.halo.exchange(world)
+                world.update(DT_NANOS)
+        else:                          # broad-phase-only: boundary AABBs against the grid the update built
             for _ in range(steps):
                 world.update(DT_NANOS)
                 self.halo.exchange(world)
@@ -463,10 +468,13 @@ def main():
             "pairs_per_sec": rec["pairs_per_sec"], "scene_stats": rec["scene_stats"],
         }
         if sharded:
-            out["config"]["cross_slab_contacts"] = ("candidate pairs across slab faces are found and counted (halo exchange), "
-                                                    "not collided or solved: each rank's narrow phase and solver see owned "
-                                                    "bodies only, so the N-rank run is N slab simulations + the exchange, "
-                                                    "not the single-world simulation cut in N")
+            out["config"]["cross_slab_contacts"] = (
+                "broad phase only: candidate pairs across slab faces are found and counted (AABB halo exchange)"
+                if not rig.halo.before_update else
+                "solved: every rank sees its neighbours' boundary bodies as kinematic ghost bodies (96-byte records, one "
+                "all-gather per step, before the update) and collides / solves its own bodies against them; a contact "
+                "across a plane is solved once per side against an immovable copy of the other body, so the N-rank run "
+                "approximates, and is not bit-identical to, the single-world simulation cut in N")
         if "roofline" in rec:
             roof = rec["roofline"]
             if not sharded:

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define PHYS_ABI_VERSION 1u
+#define PHYS_ABI_VERSION 2u
 
 /* status codes */
 #define PHYS_OK 0
@@ -70,13 +70,15 @@ typedef struct phys_config {
     float ground_height;        /* default 0 */
     float max_bias;             /* cap on the contact push-out velocity, default 3.0 */
     uint64_t max_pairs;         /* 0 = auto (24 per body) */
-    uint64_t max_manifolds;     /* 0 = auto (16 per body) */
+    uint64_t max_manifolds;     /* 0 = auto (17 per body) */
+    uint64_t max_ghosts;        /* sharded worlds: room for remote boundary bodies ("ghosts": kinematic copies of bodies owned
+                                   by neighbouring ranks, refreshed by phys_halo_exchange before every update); 0 = none */
 } phys_config;
 
 typedef struct phys_world phys_world;
 
 typedef struct phys_stats {
-    uint64_t n_bodies;
+    uint64_t n_bodies;     /* owned bodies (ghost slots not counted) */
     uint64_t n_pairs;      /* candidate pairs of the last update */
     uint64_t n_manifolds;  /* body-body + body-ground manifolds */
     uint64_t n_contacts;   /* contact points */
@@ -91,6 +93,8 @@ typedef struct phys_stats {
     float max_extent;       /* largest fattened-AABB edge of the last broad phase (the grid cell is 1.001x this) */
     uint32_t n_halo_records; /* records written by the last phys_halo_pack */
     uint64_t n_cross_pairs;  /* cross-rank pairs found by the last phys_halo_pairs */
+    uint32_t n_ghosts;       /* ghost slots filled by the last phys_halo_unpack_ghosts */
+    uint32_t pad0;
 } phys_stats;
 
 /* reference defaults (see phys_config field comments) */
@@ -205,8 +209,8 @@ typedef struct phys_device_view {
 } phys_device_view;
 int32_t phys_get_device_view(phys_world* w, phys_device_view* out);
 
-/* Sharded broad-phase. Each rank owns the bodies it was given; a halo record is
- * 32 B: {min xyz, max xyz, global id, pad}. phys_halo_pack writes to DEVICE memory the records of
+/* Sharded broad-phase, AABB records only (config C4). Each rank owns the bodies it was given; a halo
+ * record is 32 B: {min xyz, max xyz, global id, pad}. phys_halo_pack writes to DEVICE memory the records of
  * owned bodies whose fattened AABB reaches outside [x_lo + reach, x_hi - reach] and returns the count;
  * reach must be >= the largest AABB edge on ANY rank (all-reduce phys_stats.max_extent), reach <= 0
  * means this rank's own grid cell. Both calls use the AABBs / grid of the last update or phys_broadphase.
@@ -223,6 +227,63 @@ int32_t phys_halo_pack(phys_world* w, float x_lo, float x_hi, float reach, void*
 int32_t phys_halo_pairs(phys_world* w, const void* dev_remote_records, uint64_t n_remote, uint64_t skip_first,
                         uint64_t skip_count, uint64_t* n_cross_pairs);
 int32_t phys_get_cross_pairs(phys_world* w, uint32_t* pairs_out /*2*cap*/, uint64_t cap, uint64_t* n_pairs);
+
+/* Sharded worlds with contacts across the cut planes (SURVEY §8 rows E + N4; no reference counterpart: the reference is
+ * one thread on one CPU). A world created with phys_config.max_ghosts > 0 keeps max_ghosts GHOST slots behind its owned
+ * bodies. Before every update the ranks exchange the full state of their boundary bodies - a 96-byte record {pos, rot,
+ * lin vel, ang vel, half extent, shape, global id} of every owned body within `reach` of a slab face - and every rank
+ * places the neighbours' records that lie within `reach` of ITS slab into its ghost slots. A ghost is a kinematic body
+ * (inverse mass and inverse inertia 0, velocity as exchanged): the ordinary broad phase, narrow phase and solver of the
+ * update then see it like any other body, so an owned body collides with and is pushed by bodies across the plane; the
+ * ghost itself is never moved here (its owner moves it, seeing THIS rank's boundary bodies as ghosts in turn). What this
+ * is not: a contact across the plane is solved twice, once per side, each against an immovable copy of the other body
+ * (no shared impulse), so momentum across a cut plane is conserved only approximately. Ghost-ghost pairs and
+ * ghost-ground contacts are skipped. Slot order is a function of the records alone (both compactions are prefix sums,
+ * not atomics), so a sharded run repeats bit for bit.
+ *   phys_set_slab            this rank's x-interval and the reach (>= the largest bounding diameter + margin on any rank)
+ *   phys_halo_pack_bodies    owned boundary bodies -> 96-byte records in DEVICE memory (unused slots: global id 0xFFFFFFFF)
+ *   phys_halo_unpack_ghosts  gathered records (device) -> ghost slots; [skip_first, skip_first+skip_count) = own block
+ *   phys_get_global_ids      global ids of the owned bodies followed by those of the ghost slots (0xFFFFFFFF = empty);
+ *                            manifold ids >= phys_stats.n_bodies name ghost slots
+ * All three device calls only enqueue on the world's stream. */
+#define PHYS_HALO_BODY_RECORD_BYTES 96u
+int32_t phys_set_slab(phys_world* w, float x_lo, float x_hi, float reach);
+int32_t phys_halo_pack_bodies(phys_world* w, void* dev_records_out, uint64_t cap);
+int32_t phys_halo_unpack_ghosts(phys_world* w, const void* dev_records, uint64_t n_records, uint64_t skip_first,
+                                uint64_t skip_count);
+int32_t phys_get_global_ids(phys_world* w, uint32_t* out /* n_bodies + max_ghosts */);
+
+/* The exchange itself behind the C ABI: RCCL (librccl.so, loaded on first use; PHYS_RCCL_PATH overrides the search) over
+ * xGMI, one communicator rank per world / GPU, every call enqueued on the world's own stream - a Rust or C++ host shards
+ * without Python. Message shape: ONE ncclAllGather of a fixed-size block per rank (latency-bound: no count exchange).
+ *   phys_comm_unique_id   rank 0 makes the 128-byte id and ships it to the other ranks by any means
+ *   phys_comm_create      ncclCommInitRank on the world's device; `capacity` = records per rank and step
+ *   phys_comm_create_local  ONE process driving n worlds on n different devices: ncclCommInitAll (+ phys_halo_exchange_all)
+ *   phys_halo_exchange    max_ghosts > 0:  pack bodies -> all-gather -> unpack ghosts   (call BEFORE phys_update)
+ *                         otherwise:       pack AABBs  -> all-gather -> cross pairs     (call AFTER phys_update; C4) */
+#define PHYS_COMM_ID_BYTES 128u
+typedef struct phys_comm phys_comm;
+int32_t phys_comm_unique_id(uint8_t id_out[PHYS_COMM_ID_BYTES]);
+int32_t phys_comm_create(phys_world* w, const uint8_t id[PHYS_COMM_ID_BYTES], int32_t rank, int32_t n_ranks, uint64_t capacity,
+                         phys_comm** out);
+int32_t phys_comm_create_local(phys_world** worlds, int32_t n, uint64_t capacity, phys_comm** comms_out /*n*/);
+int32_t phys_comm_destroy(phys_comm* c);
+int32_t phys_halo_exchange(phys_world* w, phys_comm* c);
+/* the n collectives of a step as ONE group: required when one thread drives the comms of phys_comm_create_local */
+int32_t phys_halo_exchange_all(phys_world** worlds, phys_comm** comms, int32_t n);
+
+/* Slab partition (host arithmetic only, no device, no communication: the caller sums the histograms of the ranks with
+ * whatever transport it has - RCCL, MPI, a pipe). Equal-count cut planes along x, SURVEY §8 row E: histogram of body x
+ * over `bins` equal bins of [x_min, x_max] -> prefix sums -> n_ranks + 1 cut planes (cuts[0] = -inf side = x_min,
+ * cuts[n_ranks] = x_max; interior planes at bin boundaries... interpolated inside the bin that crosses k/n_ranks of the
+ * bodies) -> owner of every body (the rank r with cuts[r] <= x < cuts[r+1]; bodies outside [x_min, x_max] go to the
+ * first / last rank). Re-cut every k steps and hand a body that changed owner over to its new rank. */
+int32_t phys_slab_histogram(const float* pos /*3n*/, uint64_t n, float x_min, float x_max, uint32_t bins,
+                            uint64_t* hist /*bins, added to*/);
+int32_t phys_slab_cuts(const uint64_t* hist /*bins, summed over ranks*/, uint32_t bins, float x_min, float x_max, int32_t n_ranks,
+                       float* cuts_out /*n_ranks + 1*/);
+int32_t phys_slab_owners(const float* pos /*3n*/, uint64_t n, const float* cuts /*n_ranks + 1*/, int32_t n_ranks,
+                         int32_t* owner_out /*n*/);
 
 #ifdef __cplusplus
 }

@@ -311,10 +311,15 @@ PHYS_HD void collide_box_box(const geom_t* A, const geom_t* B, float margin, man
             if (s > eMax) { eMax = s; eI = i; eJ = j; }
         }
     }
-    /* prefer faces (frame coherence): an edge axis must beat the faces clearly */
+    /* prefer faces (frame coherence): an edge axis must beat the faces clearly. The tolerance scales the FACE side:
+     * with separations negative (penetration) `eMax > kRel * faceMax + kAbs` asks the edge axis to be shallower than
+     * the shallowest face by 5 % + 0.01. (Round 1 had the factor on the edge side, `kRel * eMax > faceMax + kAbs`,
+     * which for penetrations beyond 0.2 let an edge axis EQUAL to a face axis win - two axis-aligned boxes in deep
+     * face contact got one edge-edge point instead of a four-point face manifold; found by the brute-force SAT check
+     * of tests/test_gpu_independent.py.) */
     const float kRel = 0.95f, kAbs = 0.01f;
     const float faceMax = det_maxf(aMax, bMax);
-    if (eI >= 0 && kRel * eMax > faceMax + kAbs) {
+    if (eI >= 0 && eMax > kRel * faceMax + kAbs) {
         /* edge-edge */
         const v3 ai = m33_col(&A->R, eI), bj = m33_col(&B->R, eJ);
         v3 n = v3_cross(ai, bj);
@@ -351,7 +356,7 @@ PHYS_HD void collide_box_box(const geom_t* A, const geom_t* B, float margin, man
         m->depth[0] = -eMax;
         return;
     }
-    if (kRel * bMax > aMax + kAbs) {
+    if (bMax > kRel * aMax + kAbs) {
         /* reference = B; its face looks back toward A */
         const float sgn = sel3(tB, bAxis) > 0.0f ? -1.0f : 1.0f;
         const v3 nref = v3_scale(m33_col(&B->R, bAxis), sgn); /* B -> A */

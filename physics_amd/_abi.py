@@ -4,7 +4,7 @@ usable, creation fails loudly."""
 import ctypes as C
 import os
 
-PHYS_ABI_VERSION = 1
+PHYS_ABI_VERSION = 2
 
 PHYS_OK = 0
 PHYS_ERR_INVALID_ARG = -1
@@ -46,6 +46,7 @@ class PhysConfig(C.Structure):
         ("max_bias", C.c_float),
         ("max_pairs", C.c_uint64),
         ("max_manifolds", C.c_uint64),
+        ("max_ghosts", C.c_uint64),
     ]
 
 
@@ -65,6 +66,8 @@ class PhysStats(C.Structure):
         ("max_extent", C.c_float),
         ("n_halo_records", C.c_uint32),
         ("n_cross_pairs", C.c_uint64),
+        ("n_ghosts", C.c_uint32),
+        ("pad0", C.c_uint32),
     ]
 
 
@@ -110,6 +113,7 @@ def default_config(**overrides):
     cfg.max_bias = 3.0
     cfg.max_pairs = 0
     cfg.max_manifolds = 0
+    cfg.max_ghosts = 0
     for k, v in overrides.items():
         if k in ("gravity_force", "gravity_offset"):
             getattr(cfg, k)[:] = tuple(v)
@@ -155,6 +159,19 @@ PROTOTYPES = {
     "phys_halo_pack": (C.c_int32, [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_uint64, u64p]),
     "phys_halo_pairs": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, u64p]),
     "phys_get_cross_pairs": (C.c_int32, [C.c_void_p, u32p, C.c_uint64, u64p]),
+    "phys_set_slab": (C.c_int32, [C.c_void_p, C.c_float, C.c_float, C.c_float]),
+    "phys_halo_pack_bodies": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64]),
+    "phys_halo_unpack_ghosts": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64]),
+    "phys_get_global_ids": (C.c_int32, [C.c_void_p, u32p]),
+    "phys_comm_unique_id": (C.c_int32, [C.POINTER(C.c_uint8)]),
+    "phys_comm_create": (C.c_int32, [C.c_void_p, C.POINTER(C.c_uint8), C.c_int32, C.c_int32, C.c_uint64, C.POINTER(C.c_void_p)]),
+    "phys_comm_create_local": (C.c_int32, [C.POINTER(C.c_void_p), C.c_int32, C.c_uint64, C.POINTER(C.c_void_p)]),
+    "phys_comm_destroy": (C.c_int32, [C.c_void_p]),
+    "phys_halo_exchange": (C.c_int32, [C.c_void_p, C.c_void_p]),
+    "phys_halo_exchange_all": (C.c_int32, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int32]),
+    "phys_slab_histogram": (C.c_int32, [f32p, C.c_uint64, C.c_float, C.c_float, C.c_uint32, u64p]),
+    "phys_slab_cuts": (C.c_int32, [u64p, C.c_uint32, C.c_float, C.c_float, C.c_int32, f32p]),
+    "phys_slab_owners": (C.c_int32, [f32p, C.c_uint64, f32p, C.c_int32, C.POINTER(C.c_int32)]),
 }
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libphysics_hip.so")
@@ -206,6 +223,10 @@ def share_rocm_runtime_with_torch():
         path = os.path.join(d, name)
         if os.path.exists(path):
             C.CDLL(path, mode=C.RTLD_GLOBAL)
+    # the RCCL of this process must be the one built against that runtime (comm.hip loads it on first use)
+    rccl = os.path.join(d, "librccl.so")
+    if os.path.exists(rccl):
+        os.environ.setdefault("PHYS_RCCL_PATH", rccl)
     return d
 
 

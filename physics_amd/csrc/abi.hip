@@ -3,6 +3,7 @@
 // is no CPU fallback anywhere in this library.
 #include <algorithm>
 #include <cstring>
+#include <limits>
 #include <string>
 #include <vector>
 
@@ -120,6 +121,7 @@ void phys_config_default(phys_config* cfg) {
     cfg->max_bias = 3.0f;
     cfg->max_pairs = 0;
     cfg->max_manifolds = 0;
+    cfg->max_ghosts = 0;
 }
 
 const char* phys_last_error(void) { return get_error(); }
@@ -162,7 +164,7 @@ int32_t phys_destroy(phys_world* w) {
     for (auto* b : fb) b->free();
     DevBuf<uint32_t>* ub[] = {&w->shape, &w->global_id, &w->cg_status, &w->bucket_of, &w->bucket_count,
                               &w->bucket_start, &w->bucket_cursor, &w->sorted_ids, &w->slot_ids, &w->grid_ovf, &w->scan_block_sums, &w->pairs,
-                              &w->man_a, &w->man_b, &w->man_count, &w->man_color, &w->row_hdr,
+                              &w->man_a, &w->man_b, &w->man_count, &w->man_color, &w->row_hdr, &w->halo_block_counts,
                               &w->row_src, &w->cross_pairs, &w->color_block_hist, &w->cg_cols};
     for (auto* b : ub) b->free();
     w->man_prio.free(); w->color_state.free(); w->bucket_count.free(); w->step_zero.free();
@@ -186,12 +188,18 @@ int32_t phys_set_bodies(phys_world* w, uint64_t n, const float* pos, const float
     if (n && !pos) return fail(PHYS_ERR_INVALID_ARG, "pos is required");
     if (n >= 0x7FFFFFFFull) return fail(PHYS_ERR_INVALID_ARG, "too many bodies (u32 indices)");
     PHYS_HIP_TRY(hipStreamSynchronize(w->stream));
-    PHYS_HIP_TRY(w->pos.resize(3 * n)); PHYS_HIP_TRY(w->rot.resize(4 * n)); PHYS_HIP_TRY(w->vel.resize(8 * n));
-    PHYS_HIP_TRY(w->force.resize(3 * n)); PHYS_HIP_TRY(w->torque.resize(3 * n));
-    PHYS_HIP_TRY(w->inv_inertia.resize(9 * n)); PHYS_HIP_TRY(w->inv_inertia_diag.resize(4 * n));
-    PHYS_HIP_TRY(w->half_extent.resize(3 * n)); PHYS_HIP_TRY(w->aabb.resize(6 * n)); PHYS_HIP_TRY(w->shape.resize(n));
-    PHYS_HIP_TRY(w->global_id.resize(n));
-    w->n = n;
+    // sharded worlds: max_ghosts kinematic slots behind the owned bodies (filled by phys_halo_unpack_ghosts)
+    const uint64_t G = (w->cfg.flags & PHYS_FLAG_COLLISIONS) && !(w->cfg.flags & PHYS_FLAG_BROADPHASE_ONLY) ? w->cfg.max_ghosts : 0;
+    const uint64_t nt = n ? n + G : 0;
+    if (nt >= 0x7FFFFFFFull) return fail(PHYS_ERR_INVALID_ARG, "too many bodies + ghosts (u32 indices)");
+    PHYS_HIP_TRY(w->pos.resize(3 * nt)); PHYS_HIP_TRY(w->rot.resize(4 * nt)); PHYS_HIP_TRY(w->vel.resize(8 * nt));
+    PHYS_HIP_TRY(w->force.resize(3 * nt)); PHYS_HIP_TRY(w->torque.resize(3 * nt));
+    PHYS_HIP_TRY(w->inv_inertia.resize(9 * nt)); PHYS_HIP_TRY(w->inv_inertia_diag.resize(4 * nt));
+    PHYS_HIP_TRY(w->half_extent.resize(3 * nt)); PHYS_HIP_TRY(w->aabb.resize(6 * nt)); PHYS_HIP_TRY(w->shape.resize(nt));
+    PHYS_HIP_TRY(w->global_id.resize(nt));
+    w->n = nt;
+    w->n_owned = n;
+    w->max_ghosts = nt - n;
     w->forces_dirty = false;
     w->have_lambda = false;  // previous_solution: None
     w->aabbs_valid = false;
@@ -201,9 +209,10 @@ int32_t phys_set_bodies(phys_world* w, uint64_t n, const float* pos, const float
     for (int k = 0; k < phys_world::kSnapRing; ++k) w->snap_pending[k] = false;  // the stream was synchronised above
     if (n == 0) return PHYS_OK;
 
-    // host staging with RigidBody::new defaults (rigid_body.rs:64-76)
-    std::vector<float> h_rot(4 * n), h_vel(8 * n), h_inv(9 * n), h_diag(4 * n, 0.0f), h_he(3 * n, 0.0f);
-    std::vector<uint32_t> h_shape(n, PHYS_SHAPE_NONE), h_gid(n);
+    // host staging with RigidBody::new defaults (rigid_body.rs:64-76); ghost slots: no shape, immovable
+    std::vector<float> h_pos(3 * nt, 0.0f), h_rot(4 * nt), h_vel(8 * nt), h_inv(9 * nt, 0.0f), h_diag(4 * nt, 0.0f), h_he(3 * nt, 0.0f);
+    std::vector<uint32_t> h_shape(nt, PHYS_SHAPE_NONE), h_gid(nt, 0xFFFFFFFFu);
+    std::memcpy(h_pos.data(), pos, 12 * n);
     w->singular_inertia = false;
     w->all_diag_inertia = true;
     w->uniform_inertia = true;
@@ -232,17 +241,23 @@ int32_t phys_set_bodies(phys_world* w, uint64_t n, const float* pos, const float
         if (half_extent) std::memcpy(&h_he[3 * i], half_extent + 3 * i, 12);
         h_gid[i] = (uint32_t)i;
     }
+    for (uint64_t i = n; i < nt; ++i) {  // ghost slots: identity pose, inverse mass 0, mass +inf (F / m = 0), inverse inertia 0
+        h_rot[4 * i + 3] = 1.0f;
+        h_vel[8 * i + 3] = 0.0f;
+        h_vel[8 * i + 7] = std::numeric_limits<float>::infinity();
+    }
+    if (nt > n) w->uniform_inertia = false;  // the ghosts' zero tensors differ from everybody's
     hipStream_t s = w->stream;
-    PHYS_HIP_TRY(hipMemcpyAsync(w->pos.p, pos, 12 * n, hipMemcpyHostToDevice, s));
-    PHYS_HIP_TRY(hipMemcpyAsync(w->rot.p, h_rot.data(), 16 * n, hipMemcpyHostToDevice, s));
-    PHYS_HIP_TRY(hipMemcpyAsync(w->vel.p, h_vel.data(), 32 * n, hipMemcpyHostToDevice, s));
-    PHYS_HIP_TRY(hipMemsetAsync(w->force.p, 0, 12 * n, s));
-    PHYS_HIP_TRY(hipMemsetAsync(w->torque.p, 0, 12 * n, s));
-    PHYS_HIP_TRY(hipMemcpyAsync(w->inv_inertia.p, h_inv.data(), 36 * n, hipMemcpyHostToDevice, s));
-    PHYS_HIP_TRY(hipMemcpyAsync(w->inv_inertia_diag.p, h_diag.data(), 16 * n, hipMemcpyHostToDevice, s));
-    PHYS_HIP_TRY(hipMemcpyAsync(w->half_extent.p, h_he.data(), 12 * n, hipMemcpyHostToDevice, s));
-    PHYS_HIP_TRY(hipMemcpyAsync(w->shape.p, h_shape.data(), 4 * n, hipMemcpyHostToDevice, s));
-    PHYS_HIP_TRY(hipMemcpyAsync(w->global_id.p, h_gid.data(), 4 * n, hipMemcpyHostToDevice, s));
+    PHYS_HIP_TRY(hipMemcpyAsync(w->pos.p, h_pos.data(), 12 * nt, hipMemcpyHostToDevice, s));
+    PHYS_HIP_TRY(hipMemcpyAsync(w->rot.p, h_rot.data(), 16 * nt, hipMemcpyHostToDevice, s));
+    PHYS_HIP_TRY(hipMemcpyAsync(w->vel.p, h_vel.data(), 32 * nt, hipMemcpyHostToDevice, s));
+    PHYS_HIP_TRY(hipMemsetAsync(w->force.p, 0, 12 * nt, s));
+    PHYS_HIP_TRY(hipMemsetAsync(w->torque.p, 0, 12 * nt, s));
+    PHYS_HIP_TRY(hipMemcpyAsync(w->inv_inertia.p, h_inv.data(), 36 * nt, hipMemcpyHostToDevice, s));
+    PHYS_HIP_TRY(hipMemcpyAsync(w->inv_inertia_diag.p, h_diag.data(), 16 * nt, hipMemcpyHostToDevice, s));
+    PHYS_HIP_TRY(hipMemcpyAsync(w->half_extent.p, h_he.data(), 12 * nt, hipMemcpyHostToDevice, s));
+    PHYS_HIP_TRY(hipMemcpyAsync(w->shape.p, h_shape.data(), 4 * nt, hipMemcpyHostToDevice, s));
+    PHYS_HIP_TRY(hipMemcpyAsync(w->global_id.p, h_gid.data(), 4 * nt, hipMemcpyHostToDevice, s));
     if (!w->all_diag_inertia) w->uniform_inertia = false;
     PHYS_HIP_TRY(hipStreamSynchronize(s));  // staging vectors die here
     if (w->cfg.flags & PHYS_FLAG_COLLISIONS) {
@@ -255,7 +270,7 @@ int32_t phys_set_bodies(phys_world* w, uint64_t n, const float* pos, const float
 static int32_t add_constraint(phys_world* w, uint32_t kind, uint64_t body, const float t[3]) {
     ENTER(w);
     if (!t) return fail(PHYS_ERR_INVALID_ARG, "null target");
-    if (body >= w->n) return fail(PHYS_ERR_OUT_OF_RANGE, "body index out of range");
+    if (body >= w->n_owned) return fail(PHYS_ERR_OUT_OF_RANGE, "body index out of range");
     Constraint c;
     c.kind = kind; c.body = (uint32_t)body;
     c.target[0] = t[0]; c.target[1] = t[1]; c.target[2] = t[2];
@@ -280,7 +295,7 @@ int32_t phys_clear_constraints(phys_world* w) {
 static int32_t apply_force(phys_world* w, uint64_t body, int mode, const float f[3], const float arg[3]) {
     ENTER(w);
     if (!f || (mode != 0 && !arg)) return fail(PHYS_ERR_INVALID_ARG, "null argument");
-    if (body >= w->n) return fail(PHYS_ERR_OUT_OF_RANGE, "body index out of range");
+    if (body >= w->n_owned) return fail(PHYS_ERR_OUT_OF_RANGE, "body index out of range");
     launch_apply_force_one(w, (uint32_t)body, mode, f, arg);
     PHYS_HIP_TRY(hipGetLastError());
     return PHYS_OK;
@@ -297,8 +312,8 @@ int32_t phys_apply_force_at_offset(phys_world* w, uint64_t body, const float for
 
 int32_t phys_set_forces(phys_world* w, const float* force, const float* torque) {
     ENTER(w);
-    if (force) PHYS_HIP_TRY(hipMemcpyAsync(w->force.p, force, 12 * w->n, hipMemcpyHostToDevice, w->stream));
-    if (torque) PHYS_HIP_TRY(hipMemcpyAsync(w->torque.p, torque, 12 * w->n, hipMemcpyHostToDevice, w->stream));
+    if (force) PHYS_HIP_TRY(hipMemcpyAsync(w->force.p, force, 12 * w->n_owned, hipMemcpyHostToDevice, w->stream));
+    if (torque) PHYS_HIP_TRY(hipMemcpyAsync(w->torque.p, torque, 12 * w->n_owned, hipMemcpyHostToDevice, w->stream));
     PHYS_HIP_TRY(hipStreamSynchronize(w->stream));
     if (force || torque) w->forces_dirty = true;
     return PHYS_OK;
@@ -419,23 +434,23 @@ static int32_t d2h(phys_world* w, void* dst, const void* src, size_t bytes) {
 
 int32_t phys_get_transforms(phys_world* w, float* pos_out, float* rot_out) {
     ENTER(w);
-    int32_t rc = d2h(w, pos_out, w->pos.p, 12 * w->n); if (rc) return rc;
-    rc = d2h(w, rot_out, w->rot.p, 16 * w->n); if (rc) return rc;
+    int32_t rc = d2h(w, pos_out, w->pos.p, 12 * w->n_owned); if (rc) return rc;
+    rc = d2h(w, rot_out, w->rot.p, 16 * w->n_owned); if (rc) return rc;
     PHYS_HIP_TRY(hipStreamSynchronize(w->stream));
     return PHYS_OK;
 }
 int32_t phys_get_velocities(phys_world* w, float* lin_out, float* ang_out) {
     ENTER(w);
     // strided read-out of the 32-byte velocity records: 12 bytes per body from a 32-byte pitch
-    if (lin_out && w->n) PHYS_HIP_TRY(hipMemcpy2DAsync(lin_out, 12, w->vel.p, 32, 12, w->n, hipMemcpyDeviceToHost, w->stream));
-    if (ang_out && w->n) PHYS_HIP_TRY(hipMemcpy2DAsync(ang_out, 12, w->vel.p + 4, 32, 12, w->n, hipMemcpyDeviceToHost, w->stream));
+    if (lin_out && w->n_owned) PHYS_HIP_TRY(hipMemcpy2DAsync(lin_out, 12, w->vel.p, 32, 12, w->n_owned, hipMemcpyDeviceToHost, w->stream));
+    if (ang_out && w->n_owned) PHYS_HIP_TRY(hipMemcpy2DAsync(ang_out, 12, w->vel.p + 4, 32, 12, w->n_owned, hipMemcpyDeviceToHost, w->stream));
     PHYS_HIP_TRY(hipStreamSynchronize(w->stream));
     return PHYS_OK;
 }
 int32_t phys_get_forces(phys_world* w, float* force_out, float* torque_out) {
     ENTER(w);
-    int32_t rc = d2h(w, force_out, w->force.p, 12 * w->n); if (rc) return rc;
-    rc = d2h(w, torque_out, w->torque.p, 12 * w->n); if (rc) return rc;
+    int32_t rc = d2h(w, force_out, w->force.p, 12 * w->n_owned); if (rc) return rc;
+    rc = d2h(w, torque_out, w->torque.p, 12 * w->n_owned); if (rc) return rc;
     PHYS_HIP_TRY(hipStreamSynchronize(w->stream));
     return PHYS_OK;
 }
@@ -447,7 +462,7 @@ int32_t phys_get_instance_matrices(phys_world* w, float* out) {
     float* d = nullptr;
     PHYS_HIP_TRY(hipMalloc((void**)&d, 64 * w->n));
     launch_instance_matrices(w, d);
-    hipError_t e = hipMemcpyAsync(out, d, 64 * w->n, hipMemcpyDeviceToHost, w->stream);
+    hipError_t e = hipMemcpyAsync(out, d, 64 * w->n_owned, hipMemcpyDeviceToHost, w->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(w->stream);
     (void)hipFree(d);
     PHYS_HIP_TRY(e);
@@ -473,7 +488,7 @@ int32_t phys_get_aabbs(phys_world* w, float* out) {
     ENTER(w);
     if (!out) return fail(PHYS_ERR_INVALID_ARG, "null output");
     launch_aabb_only(w);
-    int32_t rc = d2h(w, out, w->aabb.p, 24 * w->n); if (rc) return rc;
+    int32_t rc = d2h(w, out, w->aabb.p, 24 * w->n_owned); if (rc) return rc;
     PHYS_HIP_TRY(hipStreamSynchronize(w->stream));
     return PHYS_OK;
 }
@@ -525,7 +540,7 @@ int32_t phys_get_stats(phys_world* w, phys_stats* out) {
     int32_t rc = fetch_counters(w); if (rc) return rc;
     std::memset(out, 0, sizeof(*out));
     const StepCounters& c = *w->h_counters;
-    out->n_bodies = w->n;
+    out->n_bodies = w->n_owned;
     out->n_pairs = c.n_pairs;
     out->n_manifolds = c.n_manifolds;
     out->n_contacts = c.n_contacts;
@@ -546,6 +561,7 @@ int32_t phys_get_stats(phys_world* w, phys_stats* out) {
     std::memcpy(&out->max_extent, &c.max_extent_bits, 4);
     out->n_halo_records = c.n_halo;
     out->n_cross_pairs = c.n_cross_pairs;
+    out->n_ghosts = c.n_ghosts;
     return PHYS_OK;
 }
 
@@ -577,7 +593,7 @@ int32_t phys_profile_get(phys_world* w, phys_profile* out) {
 int32_t phys_get_device_view(phys_world* w, phys_device_view* out) {
     ENTER(w);
     if (!out) return fail(PHYS_ERR_INVALID_ARG, "null output");
-    out->n = w->n;
+    out->n = w->n_owned;
     out->pos = w->pos.p; out->rot = w->rot.p; out->lin_vel = w->vel.p; out->ang_vel = w->vel.p + 4;  // both with a stride of 8 floats
     out->aabb = w->aabb.p;
     out->stream = (void*)w->stream;
@@ -588,7 +604,7 @@ int32_t phys_get_device_view(phys_world* w, phys_device_view* out) {
 int32_t phys_set_global_ids(phys_world* w, const uint32_t* global_ids) {
     ENTER(w);
     if (!global_ids) return fail(PHYS_ERR_INVALID_ARG, "null ids");
-    PHYS_HIP_TRY(hipMemcpyAsync(w->global_id.p, global_ids, 4 * w->n, hipMemcpyHostToDevice, w->stream));
+    PHYS_HIP_TRY(hipMemcpyAsync(w->global_id.p, global_ids, 4 * w->n_owned, hipMemcpyHostToDevice, w->stream));
     PHYS_HIP_TRY(hipStreamSynchronize(w->stream));
     return PHYS_OK;
 }
@@ -602,6 +618,28 @@ int32_t phys_halo_pairs(phys_world* w, const void* dev_remote_records, uint64_t 
                         uint64_t skip_count, uint64_t* n_cross_pairs) {
     ENTER(w);
     return halo_pairs(w, dev_remote_records, n_remote, skip_first, skip_count, n_cross_pairs);
+}
+int32_t phys_set_slab(phys_world* w, float x_lo, float x_hi, float reach) {
+    ENTER(w);
+    if (!(x_lo < x_hi) || !(reach > 0.0f)) return fail(PHYS_ERR_INVALID_ARG, "slab needs x_lo < x_hi and reach > 0");
+    w->slab_lo = x_lo; w->slab_hi = x_hi; w->slab_reach = reach;
+    return PHYS_OK;
+}
+int32_t phys_halo_pack_bodies(phys_world* w, void* dev_records_out, uint64_t cap) {
+    ENTER(w);
+    return halo_pack_bodies(w, dev_records_out, cap);
+}
+int32_t phys_halo_unpack_ghosts(phys_world* w, const void* dev_records, uint64_t n_records, uint64_t skip_first,
+                                uint64_t skip_count) {
+    ENTER(w);
+    return halo_unpack_ghosts(w, dev_records, n_records, skip_first, skip_count);
+}
+int32_t phys_get_global_ids(phys_world* w, uint32_t* out) {
+    ENTER(w);
+    if (!out) return fail(PHYS_ERR_INVALID_ARG, "null output");
+    if (w->n) PHYS_HIP_TRY(hipMemcpyAsync(out, w->global_id.p, 4 * w->n, hipMemcpyDeviceToHost, w->stream));
+    PHYS_HIP_TRY(hipStreamSynchronize(w->stream));
+    return PHYS_OK;
 }
 int32_t phys_get_cross_pairs(phys_world* w, uint32_t* pairs_out, uint64_t cap, uint64_t* n_pairs) {
     ENTER(w);

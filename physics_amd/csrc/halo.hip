@@ -186,6 +186,183 @@ __global__ __launch_bounds__(256) void k_halo_pairs(uint32_t n_remote, uint32_t 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Ghost bodies (SURVEY rows E + N4): the full state of boundary bodies crosses the cut planes, and a rank sees its
+// neighbours' boundary bodies as kinematic bodies in slots [n_owned, n_owned + max_ghosts) of its own arrays, so the
+// ordinary pipeline collides and solves against them. 96-byte record = six float4:
+//   {pos.xyz, rot.i} {rot.jkw, lin.x} {lin.yz, ang.xy} {ang.z, half.xyz} {shape, global id, 0, 0} {0, 0, 0, 0}
+// Both compactions (boundary bodies -> records, gathered records -> ghost slots) are ORDERED: a count per workgroup,
+// then every workgroup sums the counts in front of it and places its items at ballot-prefix offsets. No atomics, so
+// the record order and the ghost slot of every remote body are functions of the data alone and a sharded run repeats
+// bit for bit.
+struct BodyRecord { float4 q[6]; };
+static_assert(sizeof(BodyRecord) == PHYS_HALO_BODY_RECORD_BYTES, "body record is 96 bytes");
+
+__device__ __forceinline__ bool boundary_body(uint32_t i, uint32_t n_owned, const float* __restrict__ pos,
+                                              const uint32_t* __restrict__ shape, float x_lo, float x_hi, float reach) {
+    if (i >= n_owned || shape[i] == PHYS_SPEC_SHAPE_NONE) return false;
+    const float x = pos[3 * (size_t)i];
+    return x < x_lo + reach || x > x_hi - reach;
+}
+__device__ __forceinline__ bool ghost_record(uint32_t k, uint32_t n_records, uint32_t skip_first, uint32_t skip_count,
+                                             const BodyRecord* __restrict__ rec, float x_lo, float x_hi, float reach) {
+    if (k >= n_records || (k >= skip_first && k < skip_first + skip_count)) return false;
+    const float4 q4 = rec[k].q[4];
+    if (__float_as_uint(q4.y) == 0xFFFFFFFFu) return false;  // empty slot of a rank's block
+    const float x = rec[k].q[0].x;
+    return x >= x_lo - reach && x <= x_hi + reach;
+}
+
+// MODE 0: boundary bodies of this rank, MODE 1: gathered records that reach into this rank's slab
+template <int MODE>
+__global__ __launch_bounds__(256) void k_halo_count(uint32_t n_items, uint32_t n_owned, const float* __restrict__ pos,
+                                                    const uint32_t* __restrict__ shape, const BodyRecord* __restrict__ rec,
+                                                    uint32_t skip_first, uint32_t skip_count, float x_lo, float x_hi, float reach,
+                                                    uint32_t* __restrict__ block_counts) {
+    __shared__ uint32_t wc[4];
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    const bool take = MODE == 0 ? (i < n_items && boundary_body(i, n_owned, pos, shape, x_lo, x_hi, reach))
+                                : ghost_record(i, n_items, skip_first, skip_count, rec, x_lo, x_hi, reach);
+    const unsigned long long mask = __ballot(take);
+    if ((threadIdx.x & 63u) == 0u) wc[threadIdx.x >> 6] = (uint32_t)__popcll(mask);
+    __syncthreads();
+    if (threadIdx.x == 0) block_counts[blockIdx.x] = wc[0] + wc[1] + wc[2] + wc[3];
+}
+
+// exclusive offset of this workgroup = sum of the counts of the workgroups in front of it (a few thousand at most:
+// one strided pass); returns this lane's slot, or ~0 when the lane has nothing to place
+__device__ __forceinline__ uint32_t ordered_slot(bool take, const uint32_t* __restrict__ block_counts, uint32_t* total_out) {
+    __shared__ uint32_t s_part[4], s_wc[4], s_base;
+    uint32_t part = 0;
+    for (uint32_t b = threadIdx.x; b < blockIdx.x; b += 256u) part += block_counts[b];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) part += (uint32_t)__shfl_xor((int)part, off, 64);
+    const unsigned long long mask = __ballot(take);
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    if (lane == 0) { s_part[wave] = part; s_wc[wave] = (uint32_t)__popcll(mask); }
+    __syncthreads();
+    if (threadIdx.x == 0) s_base = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+    __syncthreads();
+    uint32_t woff = 0;
+    for (uint32_t k = 0; k < wave; ++k) woff += s_wc[k];
+    if (total_out && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *total_out = s_base + s_wc[0] + s_wc[1] + s_wc[2] + s_wc[3];
+    return take ? s_base + woff + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull)) : 0xFFFFFFFFu;
+}
+
+__global__ __launch_bounds__(256) void k_halo_pack_bodies(uint32_t n_owned, const float* __restrict__ pos,
+                                                          const float* __restrict__ rot, const float* __restrict__ vel,
+                                                          const float* __restrict__ half_extent,
+                                                          const uint32_t* __restrict__ shape,
+                                                          const uint32_t* __restrict__ global_id, float x_lo, float x_hi,
+                                                          float reach, const uint32_t* __restrict__ block_counts,
+                                                          BodyRecord* __restrict__ out, uint32_t cap, StepCounters* ctr) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    const bool take = boundary_body(i, n_owned, pos, shape, x_lo, x_hi, reach);
+    const uint32_t slot = ordered_slot(take, block_counts, &ctr->n_halo);
+    if (!take) return;
+    if (slot >= cap) { flag_overflow(ctr, 8u); return; }
+    const v3 x = ld3(pos, i), he = ld3(half_extent, i);
+    const float4 q = reinterpret_cast<const float4*>(rot)[i];
+    const BodyVel bv = ld_vel(vel, i);
+    BodyRecord r;
+    r.q[0] = make_float4(x.x, x.y, x.z, q.x);
+    r.q[1] = make_float4(q.y, q.z, q.w, bv.v.x);
+    r.q[2] = make_float4(bv.v.y, bv.v.z, bv.w.x, bv.w.y);
+    r.q[3] = make_float4(bv.w.z, he.x, he.y, he.z);
+    r.q[4] = make_float4(__uint_as_float(shape[i]), __uint_as_float(global_id[i]), 0.0f, 0.0f);
+    r.q[5] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) out[slot].q[k] = r.q[k];
+}
+
+// every ghost slot back to "nobody" before the records of this step are placed (shape NONE takes part in nothing)
+__global__ __launch_bounds__(256) void k_ghost_clear(uint32_t n_owned, uint32_t n_total, uint32_t* __restrict__ shape,
+                                                     uint32_t* __restrict__ global_id, StepCounters* ctr) {
+    const uint32_t i = n_owned + blockIdx.x * 256u + threadIdx.x;
+    if (i < n_total) { shape[i] = PHYS_SPEC_SHAPE_NONE; global_id[i] = 0xFFFFFFFFu; }
+    if (blockIdx.x == 0 && threadIdx.x == 0) ctr->n_ghosts = 0;
+}
+
+__global__ __launch_bounds__(256) void k_halo_unpack(uint32_t n_records, uint32_t skip_first, uint32_t skip_count,
+                                                     const BodyRecord* __restrict__ rec, float x_lo, float x_hi, float reach,
+                                                     const uint32_t* __restrict__ block_counts, uint32_t n_owned,
+                                                     uint32_t max_ghosts, float* __restrict__ pos, float* __restrict__ rot,
+                                                     float* __restrict__ vel, float* __restrict__ half_extent,
+                                                     uint32_t* __restrict__ shape, uint32_t* __restrict__ global_id,
+                                                     StepCounters* ctr) {
+    const uint32_t k = blockIdx.x * 256u + threadIdx.x;
+    const bool take = ghost_record(k, n_records, skip_first, skip_count, rec, x_lo, x_hi, reach);
+    const uint32_t slot = ordered_slot(take, block_counts, &ctr->n_ghosts);
+    if (!take) return;
+    if (slot >= max_ghosts) { flag_overflow(ctr, 8u); return; }
+    const uint32_t i = n_owned + slot;
+    float4 q[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) q[j] = rec[k].q[j];
+    st3(pos, i, v3_make(q[0].x, q[0].y, q[0].z));
+    reinterpret_cast<float4*>(rot)[i] = make_float4(q[0].w, q[1].x, q[1].y, q[1].z);
+    BodyVel bv;
+    bv.v = v3_make(q[1].w, q[2].x, q[2].y); bv.inv_mass = 0.0f;                 // kinematic: nothing here can push it,
+    bv.w = v3_make(q[2].z, q[2].w, q[3].x); bv.mass = __uint_as_float(0x7F800000u);  // F / m = 0 in the velocity half
+    st_vel(vel, i, bv);
+    st3(half_extent, i, v3_make(q[3].y, q[3].z, q[3].w));
+    shape[i] = __float_as_uint(q[4].x);
+    global_id[i] = __float_as_uint(q[4].y);
+}
+
+static int32_t halo_counts_room(phys_world* w, uint64_t items) {
+    const uint64_t blocks = (items + 255) / 256 + 1;
+    if (w->halo_block_counts.n < blocks) PHYS_HIP_TRY(w->halo_block_counts.resize(blocks));
+    return PHYS_OK;
+}
+
+int32_t halo_pack_bodies(phys_world* w, void* dev_out, uint64_t cap) {
+    if (!dev_out) { set_error("null argument"); return PHYS_ERR_INVALID_ARG; }
+    if (w->max_ghosts == 0) { set_error("world created without phys_config.max_ghosts"); return PHYS_ERR_UNSUPPORTED; }
+    if (!(w->slab_reach > 0.0f)) { set_error("phys_set_slab first"); return PHYS_ERR_UNSUPPORTED; }
+    if (cap >= 0xFFFFFFFFull) { set_error("record capacity exceeds u32"); return PHYS_ERR_INVALID_ARG; }
+    const uint32_t n = (uint32_t)w->n_owned;
+    const int32_t rc = halo_counts_room(w, n);
+    if (rc != PHYS_OK) return rc;
+    PHYS_PROF(w, PHYS_STAGE_MISC);
+    PHYS_HIP_TRY(hipMemsetAsync(dev_out, 0xFF, cap * sizeof(BodyRecord), w->stream));  // unused slots: global id 0xFFFFFFFF
+    if (n) {
+        const dim3 g((n + 255) / 256), b(256);
+        hipLaunchKernelGGL(k_halo_count<0>, g, b, 0, w->stream, n, n, w->pos.p, w->shape.p, (const BodyRecord*)nullptr, 0u, 0u,
+                           w->slab_lo, w->slab_hi, w->slab_reach, w->halo_block_counts.p);
+        hipLaunchKernelGGL(k_halo_pack_bodies, g, b, 0, w->stream, n, w->pos.p, w->rot.p, w->vel.p, w->half_extent.p, w->shape.p,
+                           w->global_id.p, w->slab_lo, w->slab_hi, w->slab_reach, w->halo_block_counts.p, (BodyRecord*)dev_out,
+                           (uint32_t)cap, w->counters.p);
+    }
+    PHYS_HIP_TRY(hipGetLastError());
+    return PHYS_OK;
+}
+
+int32_t halo_unpack_ghosts(phys_world* w, const void* dev_records, uint64_t n_records, uint64_t skip_first, uint64_t skip_count) {
+    if (n_records && !dev_records) { set_error("null argument"); return PHYS_ERR_INVALID_ARG; }
+    if (w->max_ghosts == 0) { set_error("world created without phys_config.max_ghosts"); return PHYS_ERR_UNSUPPORTED; }
+    if (!(w->slab_reach > 0.0f)) { set_error("phys_set_slab first"); return PHYS_ERR_UNSUPPORTED; }
+    if (n_records >= 0xFFFFFFFFull) { set_error("record count exceeds u32"); return PHYS_ERR_INVALID_ARG; }
+    const int32_t rc = halo_counts_room(w, n_records);
+    if (rc != PHYS_OK) return rc;
+    PHYS_PROF(w, PHYS_STAGE_MISC);
+    const uint32_t G = (uint32_t)w->max_ghosts, n_owned = (uint32_t)w->n_owned;
+    hipLaunchKernelGGL(k_ghost_clear, dim3((G + 255) / 256), dim3(256), 0, w->stream, n_owned, (uint32_t)w->n, w->shape.p,
+                       w->global_id.p, w->counters.p);
+    if (n_records) {
+        const dim3 g((unsigned)((n_records + 255) / 256)), b(256);
+        hipLaunchKernelGGL(k_halo_count<1>, g, b, 0, w->stream, (uint32_t)n_records, n_owned, (const float*)nullptr,
+                           (const uint32_t*)nullptr, (const BodyRecord*)dev_records, (uint32_t)skip_first, (uint32_t)skip_count,
+                           w->slab_lo, w->slab_hi, w->slab_reach, w->halo_block_counts.p);
+        hipLaunchKernelGGL(k_halo_unpack, g, b, 0, w->stream, (uint32_t)n_records, (uint32_t)skip_first, (uint32_t)skip_count,
+                           (const BodyRecord*)dev_records, w->slab_lo, w->slab_hi, w->slab_reach, w->halo_block_counts.p, n_owned, G,
+                           w->pos.p, w->rot.p, w->vel.p, w->half_extent.p, w->shape.p, w->global_id.p, w->counters.p);
+    }
+    PHYS_HIP_TRY(hipGetLastError());
+    w->aabbs_valid = false;
+    return PHYS_OK;
+}
+
 static int32_t read_counters(phys_world* w) {
     PHYS_HIP_TRY(hipMemcpyAsync(w->h_counters, w->counters.p, sizeof(StepCounters), hipMemcpyDeviceToHost, w->stream));
     PHYS_HIP_TRY(hipStreamSynchronize(w->stream));

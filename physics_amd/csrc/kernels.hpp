@@ -115,4 +115,7 @@ int32_t halo_pack(phys_world* w, float x_lo, float x_hi, float reach, void* dev_
 int32_t halo_pairs(phys_world* w, const void* dev_remote, uint64_t n_remote, uint64_t skip_first, uint64_t skip_count,
                    uint64_t* n_cross);
 
+int32_t halo_pack_bodies(phys_world* w, void* dev_out, uint64_t cap);
+int32_t halo_unpack_ghosts(phys_world* w, const void* dev_records, uint64_t n_records, uint64_t skip_first, uint64_t skip_count);
+
 }  // namespace phys

@@ -30,7 +30,8 @@ __device__ __forceinline__ geom_t load_geom(uint32_t i, const float* __restrict_
 // halves), 256 for large ones (throughput-bound: fewer, fuller workgroups)
 template <int kNpThreads>
 __global__ __launch_bounds__(kNpThreads) void k_narrowphase(
-    uint32_t n_ground /* bodies tested against the plane (0 = no ground) */, const uint32_t* __restrict__ pairs,
+    uint32_t n_ground /* bodies tested against the plane (0 = no ground) */, uint32_t n_owned /* bodies at or beyond this
+    index are ghosts of a sharded world: a pair of two ghosts belongs to other ranks */, const uint32_t* __restrict__ pairs,
     uint64_t max_pairs, const float* __restrict__ pos, const float* __restrict__ rot,
     const float* __restrict__ half_extent, const uint32_t* __restrict__ shape, float margin, float ground,
     uint64_t max_manifolds, uint32_t* __restrict__ man_a, uint32_t* __restrict__ man_b,
@@ -66,9 +67,11 @@ __global__ __launch_bounds__(kNpThreads) void k_narrowphase(
         } else if (idx < total) {
             const uint2 pr = reinterpret_cast<const uint2*>(pairs)[idx - n_ground];
             a = pr.x; b = pr.y;
-            const geom_t ga = load_geom(a, pos, rot, half_extent, shape);
-            const geom_t gb = load_geom(b, pos, rot, half_extent, shape);
-            collide_pair(&ga, &gb, margin, &m, ws);
+            if (a < n_owned) {  // a < b: both are ghosts iff a is one
+                const geom_t ga = load_geom(a, pos, rot, half_extent, shape);
+                const geom_t gb = load_geom(b, pos, rot, half_extent, shape);
+                collide_pair(&ga, &gb, margin, &m, ws);
+            }
         }
         const bool has = m.count > 0;
         const unsigned long long mask = __ballot(has);
@@ -572,7 +575,8 @@ __global__ __launch_bounds__(kColorThreads) void k_color_small(uint64_t max_mani
 void launch_narrowphase(phys_world* w) {
     const uint32_t n = (uint32_t)w->n;
     if (n == 0) return;
-    const uint32_t n_ground = (w->cfg.flags & PHYS_FLAG_GROUND_PLANE) ? n : 0u;
+    const uint32_t n_owned = (uint32_t)w->n_owned;  // ghosts rest on their owner's ground
+    const uint32_t n_ground = (w->cfg.flags & PHYS_FLAG_GROUND_PLANE) ? n_owned : 0u;
     const uint64_t work = (uint64_t)n_ground + w->max_pairs;
     // colouring state of the step: used masks + three rotating priority buffers (one memset); the narrow
     // phase publishes round 0's per-body maxima as it emits manifolds
@@ -584,7 +588,7 @@ void launch_narrowphase(phys_world* w) {
     do {                                                                                                               \
         uint64_t blocks = (work + T - 1) / T;                                                                          \
         if (blocks > 256 * 16) blocks = 256 * 16;                                                                      \
-        hipLaunchKernelGGL((k_narrowphase<T>), dim3((unsigned)blocks), dim3(T), 0, w->stream, n_ground, w->pairs.p,    \
+        hipLaunchKernelGGL((k_narrowphase<T>), dim3((unsigned)blocks), dim3(T), 0, w->stream, n_ground, n_owned, w->pairs.p, \
                            w->max_pairs, w->pos.p, w->rot.p, w->half_extent.p, w->shape.p, w->cfg.contact_margin,      \
                            w->cfg.ground_height, w->max_manifolds, w->man_a.p, w->man_b.p, w->man_count.p,             \
                            w->man_color.p, w->man_normal.p, w->man_points.p, w->man_prio.p, w->color_state.p,          \

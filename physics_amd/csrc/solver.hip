@@ -203,11 +203,13 @@ template <bool DIAG, bool EAGER = false>
 __device__ __forceinline__ void solve_row(uint32_t d, const RowArrays& rows, float friction,
                                           const float* __restrict__ inv_inertia,
                                           uint32_t inertia_stride /* 0: one tensor shared by every body */,
-                                          float* __restrict__ vel) {
+                                          float* __restrict__ vel, uint32_t ablate = 0, uint32_t n_bodies = 1) {
     RowRegs R;
     load_row<true, EAGER>(R, d, rows);
     solver_manifold_t& sm = R.sm;
-    const uint32_t a = R.a, b = R.b;
+    // PHYS_DEBUG_ABLATE (timing diagnosis, WRONG results): bit 0 - body records gathered at consecutive indices instead
+    // of the row's bodies (what the gather's scatter costs); bit 1 - no row arithmetic; bit 2 - no velocity write-back
+    const uint32_t a = (ablate & 1u) ? d % n_bodies : R.a, b = (ablate & 1u) ? (d + 7u) % n_bodies : R.b;
     const m33 IA = ld_inertia<DIAG>(inv_inertia, a * inertia_stride);
     BodyVel A = ld_vel(vel, a);
     const float ima = A.inv_mass;
@@ -221,25 +223,57 @@ __device__ __forceinline__ void solve_row(uint32_t d, const RowArrays& rows, flo
     if (sm.has_b) { IB = ld_inertia<DIAG>(inv_inertia, b * inertia_stride); B = ld_vel(vel, b); imb = B.inv_mass; vB = B.v; wB = B.w; }
     // rows made on the way: these kernels are throughput-bound and want the registers (k_solve_flow makes them all
     // beforehand, while it waits; same arithmetic)
-    solve_manifold_lazy(&sm, friction, ima, &IA, imb, &IB, &vA, &wA, &vB, &wB);
+    if (!(ablate & 2u)) solve_manifold_lazy(&sm, friction, ima, &IA, imb, &IB, &vA, &wA, &vB, &wB);
     A.v = vA; A.w = wA;
-    st_vel(vel, a, A);
-    if (sm.has_b) { B.v = vB; B.w = wB; st_vel(vel, b, B); }
+    if (!(ablate & 4u)) {
+        st_vel(vel, a, A);
+        if (sm.has_b) { B.v = vB; B.w = wB; st_vel(vel, b, B); }
+    }
 #pragma unroll
     for (int k = 0; k < 4; ++k)
         if (k < sm.count)
             rows.acc[(size_t)k * rows.cap + d] = make_float4(sm.row[k].pn, sm.row[k].pt[0], sm.row[k].pt[1], 0.0f);
 }
 
+// Tiles of `tile_rows` consecutive items handed to the workgroups of a launch so that the workgroups sharing an XCD
+// (equal blockIdx % 8 under the dispatcher's round-robin placement: a label, never relied on for correctness) cover
+// one contiguous eighth of the range. Every tile is visited exactly once for any grid size.
+struct XcdTiles {
+    uint32_t tile, last, step;
+    __device__ __forceinline__ XcdTiles(uint32_t items, uint32_t tile_rows) {
+        const uint32_t tiles = (items + tile_rows - 1) / tile_rows;
+        if (gridDim.x < 8u) {  // fewer workgroups than labels: plain striding (some labels would have nobody)
+            tile = blockIdx.x; last = tiles; step = gridDim.x;
+            return;
+        }
+        const uint32_t per = (tiles + 7u) / 8u;                       // tiles per label
+        const uint32_t label = blockIdx.x & 7u, j = blockIdx.x >> 3;  // j-th workgroup of its label
+        step = (gridDim.x - label + 7u) / 8u;                         // workgroups carrying this label
+        tile = label * per + j;
+        const uint32_t stop = (label + 1u) * per;
+        last = stop < tiles ? stop : tiles;
+    }
+    __device__ __forceinline__ bool valid() const { return tile < last; }
+    __device__ __forceinline__ void next() { tile += step; }
+};
+
 // one colour of one iteration; the row range comes from the device-side colour table
 template <bool DIAG>
 __global__ __launch_bounds__(256) void k_solve_color(const StepCounters* __restrict__ ctr, uint32_t col, RowArrays rows,
                                                      float friction, const float* __restrict__ inv_inertia,
-                                                     uint32_t inertia_stride, float* __restrict__ vel) {
+                                                     uint32_t inertia_stride, float* __restrict__ vel, uint32_t ablate,
+                                                     uint32_t n_bodies) {
     if (ctr->overflow) return;
     const uint32_t start = ctr->color_start[col], end = ctr->color_start[col + 1];
-    for (uint32_t d = start + blockIdx.x * blockDim.x + threadIdx.x; d < end; d += gridDim.x * blockDim.x)
-        solve_row<DIAG, true>(d, rows, friction, inv_inertia, inertia_stride, vel);
+    // XCD-aware tiles: the rows of a colour are in emission (= spatial) order, so a contiguous range of them touches a
+    // compact set of bodies. Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 labels the L2 they share),
+    // so the workgroups of one label take ONE contiguous eighth of the colour: the 128-byte lines of the gathered body
+    // records are then fetched into one L2 instead of into all eight (PMC, C5: 22 MB of line fetches per launch for
+    // 5.6 MB of gathered records when tiles were dealt in plain blockIdx order). Speed only: any mapping is correct.
+    for (XcdTiles t(end - start, blockDim.x); t.valid(); t.next()) {
+        const uint32_t d = start + t.tile * blockDim.x + threadIdx.x;
+        if (d < end) solve_row<DIAG, true>(d, rows, friction, inv_inertia, inertia_stride, vel, ablate, n_bodies);
+    }
 }
 
 // The colour classes [first, n_colours) of one iteration in ONE launch of ONE workgroup: colours in
@@ -687,7 +721,8 @@ __global__ __launch_bounds__(256) void k_solve_color_quad(StepCounters* ctr, uin
     // Plain arithmetic on purpose: written as `if (wave == 0) {pointers..} else if ..` over the five arrays, hipcc
     // (ROCm 7.2) lost one case of the pointer selection (wave 3 staged from a null pointer: memory access fault)
     const float4* pl = rows.all + (size_t)(4u * wave) * cap;
-    for (uint32_t base = start + blockIdx.x * kQuadRowsPerGroup; base < end; base += gridDim.x * kQuadRowsPerGroup) {
+    for (XcdTiles tl(end - start, kQuadRowsPerGroup); tl.valid(); tl.next()) {  // XCD-aware: see k_solve_color
+        const uint32_t base = start + tl.tile * kQuadRowsPerGroup;
         {
             // rows beyond `end` belong to later colours (read only, never used); beyond the arrays: clamp
             uint32_t e = base + lane;
@@ -916,6 +951,7 @@ void launch_solver(phys_world* w, float dt) {
     }
     // PHYS_DEBUG_COLOR_KERNEL=lane: the one-lane-per-manifold kernel for every colour (A/B measurements, parity tests)
     static const char* color_kernel_env = getenv("PHYS_DEBUG_COLOR_KERNEL");
+    static const uint32_t ablate = getenv("PHYS_DEBUG_ABLATE") ? (uint32_t)atoi(getenv("PHYS_DEBUG_ABLATE")) : 0u;
     // four lanes per manifold while a colour is too small to fill the chip with one lane per manifold (measured
     // crossover ~30k rows: 15k rows 10.2 vs 11.9 us per launch, 53k rows 18.3 vs 16.7, 85k rows 21.5 vs 18.7)
     constexpr uint32_t kQuadColorMaxRows = 32768;
@@ -941,10 +977,10 @@ void launch_solver(phys_world* w, float dt) {
             }
             if (diag)
                 hipLaunchKernelGGL(k_solve_color<true>, grid_for_count(h.color_count[col]), tb, 0, s, w->counters.p, col, rows,
-                                   sp.friction, inertia, stride, w->vel.p);
+                                   sp.friction, inertia, stride, w->vel.p, ablate, (uint32_t)w->n);
             else
                 hipLaunchKernelGGL(k_solve_color<false>, grid_for_count(h.color_count[col]), tb, 0, s, w->counters.p, col, rows,
-                                   sp.friction, inertia, stride, w->vel.p);
+                                   sp.friction, inertia, stride, w->vel.p, ablate, (uint32_t)w->n);
         }
         PHYS_PROF(w, PHYS_STAGE_SOLVE_TAIL);
         if (diag)

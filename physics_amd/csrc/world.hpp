@@ -80,6 +80,7 @@ struct StepCounters {
     // EARLY step of a phys_update_n batch would otherwise be gone by the time the host synchronises. Zeroed by
     // neither the per-step reset nor the extent restart (both stop short of it).
     uint32_t sticky_overflow;
+    uint32_t n_ghosts;   // ghost slots filled by the last phys_halo_unpack_ghosts (set before the update: not part of the per-step reset)
     uint32_t debug[8];  // what a kernel that refused a corrupt row saw (overflow bit 5); never read by device code
 };
 constexpr size_t kCountersStepResetBytes = offsetof(StepCounters, max_extent_bits);
@@ -153,7 +154,11 @@ struct phys_world {
     phys_config cfg;
     int device = 0;
     hipStream_t stream = nullptr;
-    uint64_t n = 0;
+    uint64_t n = 0;        // body slots the kernels run over = n_owned + max_ghosts
+    uint64_t n_owned = 0;  // bodies of phys_set_bodies: every host-facing size and index check
+    uint64_t max_ghosts = 0;
+    float slab_lo = -3.0e38f, slab_hi = 3.0e38f, slab_reach = 0.0f;  // phys_set_slab
+    phys::DevBuf<uint32_t> halo_block_counts;  // per-workgroup counts of the two ordered compactions (pack / unpack)
     uint64_t steps = 0;
     bool forces_dirty = false;      // force / torque arrays hold non-zero accumulators
     bool singular_inertia = false;  // some body's inertia tensor has det == 0 (reference panics in step)

@@ -16,11 +16,47 @@ of (local pairs, cross pairs) equals the single-world pair set (tests/test_shard
 The object handed to HaloExchange only needs halo_pack / halo_pairs / get_cross_pairs, so the host logic
 here is exercised on CPU with a stand-in world defined in the tests.
 """
+import ctypes as C
+
 import numpy as np
 
-from . import scenes
+from . import _abi, scenes
 
-RECORD_FLOATS = 8  # 32 bytes
+RECORD_FLOATS = 8  # 32 bytes: the AABB record of the broad-phase-only exchange
+BODY_RECORD_FLOATS = 24  # 96 bytes: the full-state record of the ghost exchange (PHYS_HALO_BODY_RECORD_BYTES)
+
+
+# ---- slab partition: thin wrappers over the host arithmetic of the library (phys_slab_*, no device involved) ------
+def slab_histogram(pos, x_min, x_max, bins):
+    lib = _abi.load_library()
+    pos = np.ascontiguousarray(pos, np.float32).reshape(-1, 3)
+    hist = np.zeros(bins, np.uint64)
+    rc = lib.phys_slab_histogram(pos.ctypes.data_as(_abi.f32p), len(pos), x_min, x_max, bins, hist.ctypes.data_as(_abi.u64p))
+    if rc != 0:
+        raise RuntimeError(lib.phys_last_error().decode())
+    return hist
+
+
+def slab_cuts(hist, x_min, x_max, n_ranks):
+    lib = _abi.load_library()
+    hist = np.ascontiguousarray(hist, np.uint64)
+    cuts = np.zeros(n_ranks + 1, np.float32)
+    rc = lib.phys_slab_cuts(hist.ctypes.data_as(_abi.u64p), len(hist), x_min, x_max, n_ranks, cuts.ctypes.data_as(_abi.f32p))
+    if rc != 0:
+        raise RuntimeError(lib.phys_last_error().decode())
+    return cuts
+
+
+def slab_owners(pos, cuts):
+    lib = _abi.load_library()
+    pos = np.ascontiguousarray(pos, np.float32).reshape(-1, 3)
+    cuts = np.ascontiguousarray(cuts, np.float32)
+    owner = np.zeros(len(pos), np.int32)
+    rc = lib.phys_slab_owners(pos.ctypes.data_as(_abi.f32p), len(pos), cuts.ctypes.data_as(_abi.f32p), len(cuts) - 1,
+                              owner.ctypes.data_as(C.POINTER(C.c_int32)))
+    if rc != 0:
+        raise RuntimeError(lib.phys_last_error().decode())
+    return owner
 
 
 def slab_bounds(scene_nx, spacing, rank):
@@ -120,10 +156,12 @@ class HaloExchange:
 
 
 class _BenchHalo:
-    """bench.py glue: HaloExchange + the attach arguments of one rank's scene."""
+    """bench.py glue: the exchange object + the attach arguments of one rank's scene. `before_update` says where the
+    exchange belongs in a step: ghost bodies must be in place BEFORE the update that collides with them; the AABB-only
+    exchange of the broad-phase-only workload (C4) uses the grid the update has just built."""
 
-    def __init__(self, halo, x_lo, x_hi, gids):
-        self.halo, self.x_lo, self.x_hi, self.gids = halo, x_lo, x_hi, gids
+    def __init__(self, halo, x_lo, x_hi, gids, before_update):
+        self.halo, self.x_lo, self.x_hi, self.gids, self.before_update = halo, x_lo, x_hi, gids, before_update
         self.last_cross_pairs = 0
 
     def attach(self, world, scene):
@@ -140,5 +178,128 @@ def make_rank_scene(workload, rank, world_size, dist, local_rank, pinned_host=Fa
     # boundary layers: two lattice layers per face is generous; 4x headroom
     ny_nz = sc.n // {"c1": 4, "c2": 25, "c3": 50, "c4": 100, "c5": 16, "t1m": 100}[workload]
     cap = max(4096, 16 * ny_nz)
-    halo = HaloExchange(dist, rank, world_size, f"cuda:{local_rank}", cap, pinned_host=pinned_host)
-    return sc, _BenchHalo(halo, x_lo, x_hi, gids)
+    if sc.flags & scenes.FLAG_BROADPHASE_ONLY:
+        halo = HaloExchange(dist, rank, world_size, f"cuda:{local_rank}", cap, pinned_host=pinned_host)
+        return sc, _BenchHalo(halo, x_lo, x_hi, gids, before_update=False)
+    # full step: neighbours' boundary bodies become ghosts of this rank (contacts across the cut planes)
+    sc.cfg_overrides["max_ghosts"] = 2 * cap
+    halo = GhostExchange(dist, rank, world_size, cap, transport="host" if pinned_host else "rccl")
+    return sc, _BenchHalo(halo, x_lo, x_hi, gids, before_update=True)
+
+
+class GhostExchange:
+    """Per-step exchange of a rank whose world keeps ghost bodies (phys_config.max_ghosts > 0): call exchange(world)
+    BEFORE world.update(). Afterwards the neighbours' boundary bodies sit in this world's ghost slots as kinematic
+    bodies, and the ordinary broad phase / narrow phase / solver of the update collide the owned bodies with them.
+
+    transport "rccl": everything happens behind the C ABI (phys_halo_exchange: pack kernel, ncclAllGather, unpack
+    kernel, all enqueued on the world's stream); torch.distributed only carries the 128-byte communicator id once.
+    transport "host": the same pack / unpack entry points around a torch.distributed all_gather on pinned host
+    buffers (gloo): the CPU tests with a stand-in world, and the rehearsal of N ranks on a one-GPU box."""
+
+    def __init__(self, dist, rank, world_size, cap, transport="rccl"):
+        import torch
+        self.torch, self.dist, self.rank, self.world_size, self.cap = torch, dist, rank, world_size, int(cap)
+        self.transport = transport
+        self.comm = None
+        self.x_lo = self.x_hi = self.reach = 0.0
+        if transport == "host":
+            pin = torch.cuda.is_available()
+            self.send = torch.empty((self.cap, BODY_RECORD_FLOATS), dtype=torch.float32, pin_memory=pin)
+            self.recv = torch.empty((world_size, self.cap, BODY_RECORD_FLOATS), dtype=torch.float32, pin_memory=pin)
+
+    def attach(self, world, x_lo, x_hi, global_ids, half_extent, margin):
+        """One collective at set-up: the reach must cover the largest body of ANY rank."""
+        self.x_lo, self.x_hi = float(x_lo), float(x_hi)
+        device = "cpu" if self.transport == "host" else f"cuda:{self.torch.cuda.current_device()}"
+        r = self.torch.tensor([static_reach(half_extent, margin)], dtype=self.torch.float64, device=device)
+        self.dist.all_reduce(r, op=self.dist.ReduceOp.MAX)
+        self.reach = float(r.item())
+        world.set_global_ids(global_ids)
+        world.set_slab(self.x_lo, self.x_hi, self.reach)
+        if self.transport == "rccl":
+            from .world import Comm
+            if self.comm is not None:
+                self.comm.close()
+            ids = [Comm.unique_id() if self.rank == 0 else None]
+            self.dist.broadcast_object_list(ids, src=0)
+            self.comm = Comm(world, ids[0], self.rank, self.world_size, self.cap)
+
+    def move_slab(self, world, x_lo, x_hi):
+        self.x_lo, self.x_hi = float(x_lo), float(x_hi)
+        world.set_slab(self.x_lo, self.x_hi, self.reach)
+
+    def exchange(self, world):
+        if self.transport == "rccl":
+            world.halo_exchange(self.comm)
+            return
+        world.halo_pack_bodies(self.send.data_ptr(), self.cap)
+        world.sync()
+        self.dist.all_gather_into_tensor(self.recv.view(-1, BODY_RECORD_FLOATS), self.send)
+        world.halo_unpack_ghosts(self.recv.data_ptr(), self.world_size * self.cap, self.rank * self.cap, self.cap)
+        world.sync()
+
+
+class SlabSharder:
+    """Equal-count x-slabs over the ranks, re-cut on demand (histogram of body x -> prefix sums ->
+    cut planes; every k steps), with the hand-over of every body that changed owner. The partition arithmetic is the
+    library's (phys_slab_*); the transport of histograms and body records is torch.distributed (a Rust host would use
+    its own). The hand-over goes through the host - download the rank's state, exchange the leavers, upload with
+    phys_set_bodies - which is what a re-cut every few dozen steps can afford (PCIe: 124 B per body both ways) and
+    keeps the device-side body set static between re-cuts.
+
+    `state` is a dict of per-body arrays of THIS rank: pos, rot, lin_vel, ang_vel, mass, inertia (n x 9), shape_type,
+    half_extent, gid. make_world(state) -> world builds / refills the rank's world from such a dict."""
+
+    FIELDS = (("pos", 3, np.float32), ("rot", 4, np.float32), ("lin_vel", 3, np.float32), ("ang_vel", 3, np.float32),
+              ("mass", 1, np.float32), ("inertia", 9, np.float32), ("shape_type", 1, np.uint32), ("half_extent", 3, np.float32),
+              ("gid", 1, np.uint32))
+
+    def __init__(self, dist, rank, world_size, bins=4096):
+        import torch
+        self.torch, self.dist, self.rank, self.world_size, self.bins = torch, dist, rank, world_size, bins
+        self.cuts = None
+
+    def compute_cuts(self, pos):
+        """Collective: global x-range (all-reduce min / max), summed histogram, then every rank derives the same planes."""
+        t = self.torch
+        x = np.asarray(pos, np.float32).reshape(-1, 3)[:, 0]
+        lo = t.tensor([float(x.min()) if len(x) else 3.0e38], dtype=t.float64)
+        hi = t.tensor([float(x.max()) if len(x) else -3.0e38], dtype=t.float64)
+        self.dist.all_reduce(lo, op=self.dist.ReduceOp.MIN)
+        self.dist.all_reduce(hi, op=self.dist.ReduceOp.MAX)
+        x_min, x_max = float(lo.item()) - 1.0e-3, float(hi.item()) + 1.0e-3
+        hist = t.from_numpy(slab_histogram(pos, x_min, x_max, self.bins).astype(np.int64))
+        self.dist.all_reduce(hist)
+        self.cuts = slab_cuts(hist.numpy().astype(np.uint64), x_min, x_max, self.world_size)
+        return self.cuts
+
+    def my_slab(self):
+        lo = -3.0e38 if self.rank == 0 else float(self.cuts[self.rank])
+        hi = 3.0e38 if self.rank == self.world_size - 1 else float(self.cuts[self.rank + 1])
+        return lo, hi
+
+    def migrate(self, state):
+        """Collective: every body goes to the rank whose slab holds its x. Returns this rank's new state (bodies in
+        global-id order, so the result does not depend on who sent what when)."""
+        owner = slab_owners(state["pos"], self.cuts)
+        n = len(owner)
+        width = sum(w for _, w, _ in self.FIELDS) + 1
+        rec = np.zeros((n, width), np.float64)  # exact for f32 values and u32 ids
+        c = 0
+        for name, w, _ in self.FIELDS:
+            rec[:, c:c + w] = np.asarray(state[name]).reshape(n, w)
+            c += w
+        rec[:, c] = owner
+        gathered = [None] * self.world_size
+        self.dist.all_gather_object(gathered, rec[owner != self.rank])
+        mine = [rec[owner == self.rank]] + [g[g[:, -1] == self.rank] for r, g in enumerate(gathered) if r != self.rank and len(g)]
+        allrec = np.concatenate(mine) if mine else rec[:0]
+        gid_col = sum(w for _, w, _ in self.FIELDS[:-1])
+        allrec = allrec[np.argsort(allrec[:, gid_col], kind="stable")]
+        out, c = {}, 0
+        for name, w, dt in self.FIELDS:
+            a = allrec[:, c:c + w].astype(dt)
+            out[name] = a.reshape(-1) if w == 1 else a
+            c += w
+        return out

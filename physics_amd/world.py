@@ -214,3 +214,55 @@ class World:
         if n.value:
             self._ck(self.lib.phys_get_cross_pairs(self.h, _p(out, u32p), n.value, C.byref(n)))
         return out
+
+    # ---- sharded worlds with ghost bodies (SURVEY §8 rows E + N4)
+    def set_slab(self, x_lo, x_hi, reach):
+        self._ck(self.lib.phys_set_slab(self.h, x_lo, x_hi, reach))
+
+    def halo_pack_bodies(self, dev_ptr, cap):
+        self._ck(self.lib.phys_halo_pack_bodies(self.h, C.c_void_p(dev_ptr), cap))
+
+    def halo_unpack_ghosts(self, dev_ptr, n_records, skip_first=0, skip_count=0):
+        self._ck(self.lib.phys_halo_unpack_ghosts(self.h, C.c_void_p(dev_ptr), n_records, skip_first, skip_count))
+
+    def get_global_ids(self):
+        out = np.empty(self.n + int(self.cfg.max_ghosts), np.uint32)
+        self._ck(self.lib.phys_get_global_ids(self.h, _p(out, u32p)))
+        return out
+
+    def halo_exchange(self, comm):
+        """pack -> RCCL all-gather -> unpack (ghost worlds: call BEFORE update) / cross pairs (AABB mode: AFTER)."""
+        self._ck(self.lib.phys_halo_exchange(self.h, comm.h))
+
+
+class Comm:
+    """One rank of an RCCL communicator behind the C ABI (phys_comm_*): the id travels by whatever the host has."""
+
+    @staticmethod
+    def unique_id():
+        lib = _abi.load_library()
+        buf = (C.c_uint8 * 128)()
+        rc = lib.phys_comm_unique_id(buf)
+        if rc != 0:
+            raise PhysError(rc, lib.phys_last_error().decode())
+        return bytes(buf)
+
+    def __init__(self, world, unique_id, rank, n_ranks, capacity):
+        self.lib = world.lib
+        self.h = C.c_void_p()
+        self.rank, self.n_ranks, self.capacity = rank, n_ranks, capacity
+        buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        rc = self.lib.phys_comm_create(world.h, buf, rank, n_ranks, capacity, C.byref(self.h))
+        if rc != 0:
+            raise PhysError(rc, self.lib.phys_last_error().decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.phys_comm_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

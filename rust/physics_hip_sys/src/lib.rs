@@ -1,9 +1,10 @@
 //! Raw bindings of include/physics_hip.h (UNCOMPILED SOURCE: no Rust toolchain on the build machines).
-//! One `extern "C"` item per symbol the header declares, same order, same types.
+//! One `extern "C"` item per symbol the header declares, same order, same types (tests/test_abi.py checks the list
+//! against the header: every phys_* symbol of physics_hip.h appears here exactly once).
 #![allow(non_camel_case_types)]
 use std::os::raw::{c_char, c_void};
 
-pub const PHYS_ABI_VERSION: u32 = 1;
+pub const PHYS_ABI_VERSION: u32 = 2;
 pub const PHYS_OK: i32 = 0;
 pub const PHYS_ERR_SINGULAR_INERTIA: i32 = -4;
 pub const PHYS_ERR_NO_BODIES: i32 = -8;
@@ -36,6 +37,7 @@ pub struct phys_config {
     pub max_bias: f32,
     pub max_pairs: u64,
     pub max_manifolds: u64,
+    pub max_ghosts: u64,
 }
 
 #[repr(C)]
@@ -55,11 +57,43 @@ pub struct phys_stats {
     pub max_extent: f32,
     pub n_halo_records: u32,
     pub n_cross_pairs: u64,
+    pub n_ghosts: u32,
+    pub pad0: u32,
 }
 
 #[repr(C)]
 pub struct phys_world {
     _private: [u8; 0],
+}
+
+#[repr(C)]
+pub struct phys_comm {
+    _private: [u8; 0],
+}
+
+pub const PHYS_STAGE_COUNT: usize = 13;
+pub const PHYS_COMM_ID_BYTES: usize = 128;
+pub const PHYS_HALO_BODY_RECORD_BYTES: usize = 96;
+
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct phys_profile {
+    pub ms: [f64; PHYS_STAGE_COUNT],
+    pub launches: [u64; PHYS_STAGE_COUNT],
+    pub steps: u64,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct phys_device_view {
+    pub n: u64,
+    pub pos: *mut f32,
+    pub rot: *mut f32,
+    pub lin_vel: *mut f32,
+    pub ang_vel: *mut f32,
+    pub aabb: *mut f32,
+    pub stream: *mut c_void,
+    pub vel_stride: u64,
 }
 
 extern "C" {
@@ -94,10 +128,28 @@ extern "C" {
                               points_out: *mut f32, cap: u64, n_manifolds: *mut u64) -> i32;
     pub fn phys_get_stats(w: *mut phys_world, out: *mut phys_stats) -> i32;
     pub fn phys_get_color_counts(w: *mut phys_world, counts_out: *mut u32) -> i32;
+    pub fn phys_profile_enable(w: *mut phys_world, on: i32) -> i32;
+    pub fn phys_profile_get(w: *mut phys_world, out: *mut phys_profile) -> i32;
+    pub fn phys_get_device_view(w: *mut phys_world, out: *mut phys_device_view) -> i32;
     pub fn phys_set_global_ids(w: *mut phys_world, global_ids: *const u32) -> i32;
     pub fn phys_halo_pack(w: *mut phys_world, x_lo: f32, x_hi: f32, reach: f32, dev_records_out: *mut c_void, cap: u64,
                           n_records: *mut u64) -> i32;
     pub fn phys_halo_pairs(w: *mut phys_world, dev_remote_records: *const c_void, n_remote: u64, skip_first: u64,
                            skip_count: u64, n_cross_pairs: *mut u64) -> i32;
     pub fn phys_get_cross_pairs(w: *mut phys_world, pairs_out: *mut u32, cap: u64, n_pairs: *mut u64) -> i32;
+    pub fn phys_set_slab(w: *mut phys_world, x_lo: f32, x_hi: f32, reach: f32) -> i32;
+    pub fn phys_halo_pack_bodies(w: *mut phys_world, dev_records_out: *mut c_void, cap: u64) -> i32;
+    pub fn phys_halo_unpack_ghosts(w: *mut phys_world, dev_records: *const c_void, n_records: u64, skip_first: u64,
+                                   skip_count: u64) -> i32;
+    pub fn phys_get_global_ids(w: *mut phys_world, out: *mut u32) -> i32;
+    pub fn phys_comm_unique_id(id_out: *mut u8) -> i32;
+    pub fn phys_comm_create(w: *mut phys_world, id: *const u8, rank: i32, n_ranks: i32, capacity: u64,
+                            out: *mut *mut phys_comm) -> i32;
+    pub fn phys_comm_create_local(worlds: *mut *mut phys_world, n: i32, capacity: u64, comms_out: *mut *mut phys_comm) -> i32;
+    pub fn phys_comm_destroy(c: *mut phys_comm) -> i32;
+    pub fn phys_halo_exchange(w: *mut phys_world, c: *mut phys_comm) -> i32;
+    pub fn phys_halo_exchange_all(worlds: *mut *mut phys_world, comms: *mut *mut phys_comm, n: i32) -> i32;
+    pub fn phys_slab_histogram(pos: *const f32, n: u64, x_min: f32, x_max: f32, bins: u32, hist: *mut u64) -> i32;
+    pub fn phys_slab_cuts(hist: *const u64, bins: u32, x_min: f32, x_max: f32, n_ranks: i32, cuts_out: *mut f32) -> i32;
+    pub fn phys_slab_owners(pos: *const f32, n: u64, cuts: *const f32, n_ranks: i32, owner_out: *mut i32) -> i32;
 }

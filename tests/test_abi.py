@@ -91,3 +91,21 @@ def test_product_code_never_touches_the_oracle():
                     if re.search(r"^\s*(from|import)\s+oracle|liboracle|#\s*include\s*[<\"][^>\"]*oracle|\boracle_[a-z_]+\s*\(", txt, flags=re.M):
                         bad.append(os.path.join(d, f))
     assert not bad, bad
+
+
+def test_independent_gpu_checks_share_no_code_with_the_spec_or_the_oracle():
+    """tests/test_gpu_independent.py is the one place where the collision arithmetic is checked against something
+    that is NOT compiled from include/spec: it may import numpy, pytest and the product's Python host, nothing else."""
+    txt = open(os.path.join(ROOT, "tests", "test_gpu_independent.py")).read()
+    mods = set(re.findall(r"^\s*(?:from|import)\s+([A-Za-z0-9_\.]+)", txt, flags=re.M))
+    assert mods <= {"numpy", "pytest", "physics_amd"}, mods
+    assert "liboracle" not in txt and "include/spec" not in txt.split('"""')[2]
+
+
+def test_rust_shim_declares_every_header_symbol_once():
+    """rust/physics_hip_sys/src/lib.rs is uncompiled source (no cargo / rustc in the image); at least its extern block
+    must name exactly the symbols of include/physics_hip.h."""
+    txt = open(os.path.join(ROOT, "rust", "physics_hip_sys", "src", "lib.rs")).read()
+    rust = re.findall(r"pub fn (phys_[a-z0-9_]+)\s*\(", txt)
+    assert sorted(rust) == _declared_symbols(), sorted(set(_declared_symbols()) ^ set(rust))
+    assert "pub const PHYS_ABI_VERSION: u32 = %d;" % _abi.PHYS_ABI_VERSION in txt

@@ -1,0 +1,179 @@
+"""GPU: sharded worlds with contacts across the cut plane (SURVEY §8 rows E + N4) through the C ABI.
+
+Two worlds on ONE GPU stand for two ranks (RCCL wants one rank per GPU, so the all-gather between them is a device
+copy made by the test; the RCCL entry points themselves are driven with a one-rank communicator at the end). Each step:
+phys_halo_pack_bodies on both -> "all-gather" -> phys_halo_unpack_ghosts on both -> phys_update on both.
+Checked: boundary bodies arrive as ghosts with the right global ids; manifolds against ghosts exist; bodies owned by
+different ranks do not pass through each other (they do without the exchange: the control); a sharded run repeats bit
+for bit (ordered compaction, no atomics)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+DT = 16_666_667
+REC = 96  # PHYS_HALO_BODY_RECORD_BYTES
+
+
+def _make(pos, vel, gids, x_lo, x_hi, ground, cap, gravity=(0.0, -9.81, 0.0)):
+    import physics_amd
+    flags = physics_amd.FLAG_COLLISIONS | (physics_amd.FLAG_GROUND_PLANE if ground else 0)
+    cfg = physics_amd.default_config(flags=flags, gravity_offset=(0, 0, 0), gravity_force=gravity, max_ghosts=2 * cap)
+    w = physics_amd.World(cfg)
+    n = len(pos)
+    w.set_bodies(pos, lin_vel=vel, shape_type=np.full(n, physics_amd.SHAPE_BOX, np.uint32), half_extent=np.ones((n, 3), np.float32))
+    w.set_global_ids(gids)
+    w.set_slab(x_lo, x_hi, 4.0)  # reach: cube diagonal 3.47 + margins
+    return w
+
+
+class TwoRanks:
+    """Left world owns x < 0, right world x >= 0; exchange() plays the all-gather with device copies."""
+
+    def __init__(self, pos, vel, ground=True, exchange=True, cap=1024, gravity=(0.0, -9.81, 0.0)):
+        import torch
+        self.torch = torch
+        left = pos[:, 0] < 0
+        self.idx = [np.nonzero(left)[0], np.nonzero(~left)[0]]
+        self.worlds = [_make(pos[self.idx[0]], vel[self.idx[0]], self.idx[0].astype(np.uint32), -1.0e6, 0.0, ground, cap, gravity),
+                       _make(pos[self.idx[1]], vel[self.idx[1]], self.idx[1].astype(np.uint32), 0.0, 1.0e6, ground, cap, gravity)]
+        self.cap = cap
+        self.send = [torch.empty(cap * REC, dtype=torch.uint8, device="cuda") for _ in range(2)]
+        self.do_exchange = exchange
+        self.n_total = len(pos)
+
+    def step(self, k=1):
+        torch = self.torch
+        for _ in range(k):
+            if self.do_exchange:
+                for w, buf in zip(self.worlds, self.send):
+                    w.halo_pack_bodies(buf.data_ptr(), self.cap)
+                for w in self.worlds:
+                    w.sync()
+                gathered = torch.cat(self.send)  # rank-major blocks, as ncclAllGather lays them out
+                torch.cuda.synchronize()
+                for r, w in enumerate(self.worlds):
+                    w.halo_unpack_ghosts(gathered.data_ptr(), 2 * self.cap, r * self.cap, self.cap)
+                for w in self.worlds:
+                    w.sync()  # `gathered` may be freed after this
+            for w in self.worlds:
+                w.update(DT)
+        for w in self.worlds:
+            w.sync()
+
+    def positions(self):
+        out = np.zeros((self.n_total, 3), np.float32)
+        for ids, w in zip(self.idx, self.worlds):
+            out[ids] = w.get_transforms()[0]
+        return out
+
+    def state(self):
+        return [a for w in self.worlds for a in w.get_transforms() + w.get_velocities()]
+
+    def close(self):
+        for w in self.worlds:
+            w.close()
+
+
+def test_head_on_across_the_plane_bounces_with_ghosts_and_passes_through_without():
+    pos = np.array([[-3.0, 5.0, 0.0], [3.0, 5.0, 0.0]], np.float32)
+    vel = np.array([[4.0, 0.0, 0.0], [-4.0, 0.0, 0.0]], np.float32)
+    for exchange in (True, False):
+        t = TwoRanks(pos, vel, ground=False, exchange=exchange, gravity=(0.0, 0.0, 0.0))
+        t.step(1)
+        if exchange:
+            for r, w in enumerate(t.worlds):
+                st = w.get_stats()
+                assert st.n_ghosts == 1 and st.n_bodies == 1
+                gid = w.get_global_ids()
+                assert gid[0] == r and gid[1] == 1 - r, gid[:3]  # own body, then the neighbour's as the first ghost
+        t.step(119)
+        x = t.positions()[:, 0]
+        if exchange:
+            assert x[0] < x[1] - 1.9, f"cubes of different ranks ended up inside each other: {x}"
+            lin = [w.get_velocities()[0][0] for w in t.worlds]
+            assert lin[0][0] < 0 < lin[1][0], "each cube was turned back by the other rank's cube"
+        else:
+            assert x[0] > x[1], "control: without the exchange the two ranks do not see each other"
+        t.close()
+
+
+def _two_piles():
+    from physics_amd import scenes
+    pos = scenes.lattice(8, 3, 4, 2.5, 2.0, 0.05)
+    vel = np.zeros_like(pos)
+    vel[:, 0] = np.where(pos[:, 0] < 0, 1.5, -1.5)  # the two halves drift into each other while they fall
+    return pos, vel
+
+
+def _min_cross_distance(t):
+    p = t.positions().astype(np.float64)
+    a, b = p[t.idx[0]], p[t.idx[1]]
+    d = np.linalg.norm(a[:, None, :] - b[None, :, :], axis=2)
+    return float(d.min())
+
+
+def test_piles_meeting_at_the_plane_do_not_interpenetrate_and_runs_repeat_bit_for_bit():
+    pos, vel = _two_piles()
+    runs = []
+    for _ in range(2):
+        t = TwoRanks(pos, vel)
+        ghost_contacts = 0
+        for _chunk in range(24):  # the halves meet, push each other back and settle: contacts across the plane come and go
+            t.step(10)
+            st = [w.get_stats() for w in t.worlds]
+            assert all(s.overflow == 0 for s in st)
+            ids = t.worlds[0].get_manifolds()[0]
+            n_owned = st[0].n_bodies
+            ghost_contacts += int(((ids[:, 1] >= n_owned) & (ids[:, 1] != 0xFFFFFFFF)).sum())
+            assert (ids[:, 0] < n_owned).all(), "a ghost-ghost or ghost-ground manifold was generated"
+        assert sum(s.n_ghosts for s in st) > 0, "nobody near the plane?"
+        assert ghost_contacts > 0, "no manifold against a ghost on rank 0 at any of the sampled steps"
+        # two unit cubes touch at a centre distance of 2 (face to face) or more: 1.8 allows slop + solver softness
+        assert _min_cross_distance(t) > 1.8
+        runs.append(t.state())
+        t.close()
+    for a, b in zip(runs[0], runs[1]):
+        assert np.array_equal(a, b), "the sharded run is not reproducible"
+    control = TwoRanks(pos, vel, exchange=False)
+    control.step(240)
+    assert _min_cross_distance(control) < 1.5, "control: the halves should have slid into each other"
+    control.close()
+
+
+def test_ghost_capacity_overflow_is_reported():
+    import physics_amd
+    pos, vel = _two_piles()
+    t = TwoRanks(pos, vel, cap=1024)
+    # shrink the ghost room of rank 0 below its share of boundary bodies
+    t.worlds[0].close()
+    cfg_small = physics_amd.default_config(flags=physics_amd.FLAG_COLLISIONS | physics_amd.FLAG_GROUND_PLANE,
+                                           gravity_offset=(0, 0, 0), max_ghosts=2)
+    w = physics_amd.World(cfg_small)
+    ids = t.idx[0]
+    w.set_bodies(pos[ids], lin_vel=vel[ids], shape_type=np.full(len(ids), physics_amd.SHAPE_BOX, np.uint32),
+                 half_extent=np.ones((len(ids), 3), np.float32))
+    w.set_global_ids(ids.astype(np.uint32))
+    w.set_slab(-1.0e6, 0.0, 4.0)
+    t.worlds[0] = w
+    with pytest.raises(physics_amd.PhysError) as e:
+        t.step(1)  # the unpack of rank 0 finds more boundary bodies of rank 1 than it has ghost slots
+    assert e.value.code == -5
+    t.close()
+
+
+def test_rccl_exchange_behind_the_c_abi_with_one_rank():
+    """phys_comm_* / phys_halo_exchange: librccl is loaded by the library, ncclCommInitRank + ncclAllGather run on the
+    world's own stream. With one rank the gathered buffer is the rank's own block, which unpack skips: no ghosts, but
+    the boundary bodies were packed and the collective completed."""
+    import physics_amd
+    pos, vel = _two_piles()
+    w = _make(pos, vel, np.arange(len(pos), dtype=np.uint32), -2.0, 2.0, True, 256)
+    comm = physics_amd.Comm(w, physics_amd.Comm.unique_id(), 0, 1, 256)
+    for _ in range(80):  # long enough for the lowest layer to land
+        w.halo_exchange(comm)
+        w.update(DT)
+    w.sync()
+    st = w.get_stats()
+    assert st.n_ghosts == 0 and st.overflow == 0 and st.n_manifolds > 0
+    comm.close()
+    w.close()

@@ -20,6 +20,11 @@ VARIANTS = {
     "auto": {"PHYS_DEBUG_FLOW_MAX": "0"},
     "flow": {"PHYS_DEBUG_FLOW_MAX": "100000000"},
     "default": {},
+    # timing diagnosis of the one-lane per-colour kernel (results are WRONG by construction: hashes differ)
+    "nogather": {"PHYS_DEBUG_COLOR_KERNEL": "lane", "PHYS_DEBUG_FLOW_MAX": "0", "PHYS_DEBUG_ABLATE": "1"},
+    "nocompute": {"PHYS_DEBUG_COLOR_KERNEL": "lane", "PHYS_DEBUG_FLOW_MAX": "0", "PHYS_DEBUG_ABLATE": "2"},
+    "nostore": {"PHYS_DEBUG_COLOR_KERNEL": "lane", "PHYS_DEBUG_FLOW_MAX": "0", "PHYS_DEBUG_ABLATE": "4"},
+    "loadonly": {"PHYS_DEBUG_COLOR_KERNEL": "lane", "PHYS_DEBUG_FLOW_MAX": "0", "PHYS_DEBUG_ABLATE": "7"},
 }
 
 

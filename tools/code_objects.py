@@ -70,7 +70,17 @@ def count_instructions(lib, mnemonics):
 
 if __name__ == "__main__":
     here = os.path.dirname(os.path.abspath(__file__))
-    lib = sys.argv[1] if len(sys.argv) > 1 else os.path.join(here, "..", "physics_amd", "csrc", "libphysics_hip.so")
+    args = [a for a in sys.argv[1:] if a != "--check"]
+    lib = args[0] if args else os.path.join(here, "..", "physics_amd", "csrc", "libphysics_hip.so")
+    if "--check" in sys.argv:
+        # the build's own gate (csrc/Makefile): the two rules of DESIGN.md section 8 hold on the code objects just linked,
+        # or the build FAILS - a compiler update that drops the -packed-fp32-ops feature must not pass as a warning
+        packed = count_instructions(lib, ("v_pk_mul_f32", "v_pk_add_f32", "v_pk_fma_f32"))
+        bad = [(k["name"], k["scratch"], k["spills"]) for k in kernels(lib) if k["scratch"] or k["spills"]]
+        if packed or bad:
+            print(f"code object rules violated: {packed} packed fp32 arithmetic instructions; scratch / spills: {bad}", file=sys.stderr)
+            sys.exit(1)
+        sys.exit(0)
     ks = kernels(lib)
     for k in sorted(ks, key=lambda k: k["name"]):
         short = subprocess.run(["c++filt", k["name"]], capture_output=True, text=True).stdout.split("(")[0].strip()
