@@ -47,7 +47,7 @@ KERNEL_OF_STAGE = {
     "color": "k_color_small",  # small scenes; larger ones: k_color_round x rounds + k_color_finish
     "rows": "k_rows_build",    # + k_color_hist / k_color_offsets / k_color_place beyond 40k manifolds
     "solve": "k_solve_color",  # k_solve_color_quad (four lanes per manifold) unless PHYS_DEBUG_COLOR_KERNEL=lane
-    "solve_tail": "k_solve_tail", "solve_flow": "k_solve_flow", "position": "k_step_position",
+    "solve_tail": "k_solve_tail", "solve_flow": "k_solve_flow", "solve_cluster": "k_solve_cluster", "position": "k_step_position",
 }
 
 DEFAULT_PREROLL = {"c1": 100, "c2": 150, "c3": 150, "c5": 30, "t1m": 100, "c4": 0}
@@ -73,7 +73,7 @@ def stage_bytes(stage, st, iters):
         return 28 * m  # ids + priority + colour + slot, once
     if stage == "rows":
         return 100 * m + 24 * m + 76 * k + 52 * (m + mb)
-    if stage in ("solve", "solve_flow"):
+    if stage in ("solve", "solve_flow", "solve_cluster"):
         # (k_solve_flow makes all iterations in one launch; same job, same compulsory bytes)
         # per body and iteration: v, w read 24 + written 24, inverse mass 4, inverse inertia diagonal 12
         # (all benchmark scenes have diagonal tensors; 36 with a full tensor)

@@ -186,7 +186,8 @@ int32_t phys_get_color_counts(phys_world* w, uint32_t* counts_out /*64*/);
 #define PHYS_STAGE_MISC 10u         /* memsets, halo */
 #define PHYS_STAGE_SOLVE_TAIL 11u   /* k_solve_tail: the small colours of one iteration in one workgroup */
 #define PHYS_STAGE_SOLVE_FLOW 12u   /* k_solve_flow: all iterations and colours in one launch */
-#define PHYS_STAGE_COUNT 13u
+#define PHYS_STAGE_SOLVE_CLUSTER 13u /* k_solve_cluster: one launch, body velocities resident in LDS per spatial cluster */
+#define PHYS_STAGE_COUNT 14u
 typedef struct phys_profile {
     double ms[PHYS_STAGE_COUNT];         /* summed device time per stage since enable */
     uint64_t launches[PHYS_STAGE_COUNT]; /* kernel launches (memsets included) per stage */

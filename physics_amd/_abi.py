@@ -71,9 +71,9 @@ class PhysStats(C.Structure):
     ]
 
 
-STAGE_COUNT = 13
+STAGE_COUNT = 14
 STAGE_NAMES = ["step_full", "velocity_aabb", "grid", "pairs", "narrow", "color", "rows", "solve", "position",
-               "constraints", "misc", "solve_tail", "solve_flow"]
+               "constraints", "misc", "solve_tail", "solve_flow", "solve_cluster"]
 
 
 class PhysProfile(C.Structure):

@@ -165,6 +165,7 @@ int32_t phys_destroy(phys_world* w) {
     DevBuf<uint32_t>* ub[] = {&w->shape, &w->global_id, &w->cg_status, &w->bucket_of, &w->bucket_count,
                               &w->bucket_start, &w->bucket_cursor, &w->sorted_ids, &w->slot_ids, &w->grid_ovf, &w->scan_block_sums, &w->pairs,
                               &w->man_a, &w->man_b, &w->man_count, &w->man_color, &w->row_hdr, &w->halo_block_counts,
+                              &w->cluster_slot, &w->cluster_body, &w->body_shared, &w->seg_count, &w->seg_start, &w->man_rank,
                               &w->row_src, &w->cross_pairs, &w->color_block_hist, &w->cg_cols};
     for (auto* b : ub) b->free();
     w->man_prio.free(); w->color_state.free(); w->bucket_count.free(); w->step_zero.free();
@@ -261,8 +262,12 @@ int32_t phys_set_bodies(phys_world* w, uint64_t n, const float* pos, const float
     if (!w->all_diag_inertia) w->uniform_inertia = false;
     PHYS_HIP_TRY(hipStreamSynchronize(s));  // staging vectors die here
     if (w->cfg.flags & PHYS_FLAG_COLLISIONS) {
-        const int32_t rc = collision_alloc(w);
+        int32_t rc = collision_alloc(w);
         if (rc != PHYS_OK) return rc;
+        if (!(w->cfg.flags & PHYS_FLAG_BROADPHASE_ONLY)) {
+            rc = cluster_assign(w, pos);  // spatial clusters of the cluster solver (large scenes only)
+            if (rc != PHYS_OK) return rc;
+        }
     }
     return PHYS_OK;
 }

@@ -542,7 +542,7 @@ int32_t collision_alloc(phys_world* w) {
     PHYS_HIP_TRY(w->bucket_of.resize(n));
     PHYS_HIP_TRY(w->bucket_cursor.resize(n));  // rank of each body inside its bucket
     PHYS_HIP_TRY(w->bucket_start.resize((size_t)T + 1));
-    PHYS_HIP_TRY(w->scan_block_sums.resize((T + kScanChunk - 1) / kScanChunk + 1));
+    PHYS_HIP_TRY(w->scan_block_sums.resize(std::max<size_t>((T + kScanChunk - 1) / kScanChunk + 1, 64)));
     PHYS_HIP_TRY(w->sorted_ids.resize(n));
     PHYS_HIP_TRY(w->slot_ids.resize((size_t)kSlotsPerBucket * T));
     PHYS_HIP_TRY(w->slot_box.resize((size_t)6 * kSlotsPerBucket * T));
@@ -585,6 +585,19 @@ int32_t collision_alloc(phys_world* w) {
         }
     }
     return PHYS_OK;
+}
+
+// exclusive scan of `count` (a multiple of 4) counters into out[count + 1] on the world's stream
+void launch_exclusive_scan(phys_world* w, const uint32_t* in, uint32_t count, uint32_t* out) {
+    hipStream_t s = w->stream;
+    if (count <= (uint32_t)(kScanSmallThreads * kScanSmallItems)) {
+        hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(kScanSmallThreads), 0, s, in, count, out);
+        return;
+    }
+    const uint32_t nblk = (count + kScanChunk - 1) / kScanChunk;
+    hipLaunchKernelGGL(k_scan_reduce, dim3(nblk), dim3(kScanThreads), 0, s, in, count, w->scan_block_sums.p);
+    hipLaunchKernelGGL(k_scan_block_sums, dim3(1), dim3(1024), 0, s, w->scan_block_sums.p, nblk);
+    hipLaunchKernelGGL(k_scan_final, dim3(nblk), dim3(kScanThreads), 0, s, in, count, w->scan_block_sums.p, out);
 }
 
 void zero_step_state(phys_world* w, bool including_extent) {

@@ -48,6 +48,24 @@ __device__ __forceinline__ void st_vel(float* __restrict__ vel, uint32_t i, cons
     reinterpret_cast<float4*>(vel)[2 * (size_t)i + 1] = make_float4(r.w.x, r.w.y, r.w.z, r.mass);
 }
 
+// inverse inertia of one body. DIAG: every body's tensor is diagonal (the reference's only case: identity,
+// rigid_body.rs:71), stored as one float4 per body = 16 B and one sector per gather instead of 36 B / two.
+// The zero off-diagonals are put back, so the arithmetic is the general path's (only signed zeros can differ).
+template <bool DIAG>
+__device__ __forceinline__ m33 ld_inertia_c(const float* __restrict__ p, uint32_t i) {
+    m33 M;
+    if (DIAG) {
+        const float4 d = reinterpret_cast<const float4*>(p)[i];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) M.m[k] = 0.0f;
+        M.m[0] = d.x; M.m[4] = d.y; M.m[8] = d.z;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) M.m[k] = p[9 * (size_t)i + k];
+    }
+    return M;
+}
+
 // Persistent colouring: hash table (a << 32 | b) -> colour of this update's manifolds, looked up by the next
 // update's narrow phase. Open addressing, linear probing; the table has at least 1.5 slots per manifold SLOT of the
 // world, so an insert always finds room. The layout depends on arrival order, the answers (exact key matches) do
@@ -114,6 +132,13 @@ void launch_constraint_phase(phys_world* w);
 int32_t halo_pack(phys_world* w, float x_lo, float x_hi, float reach, void* dev_out, uint64_t cap, uint64_t* n_records);
 int32_t halo_pairs(phys_world* w, const void* dev_remote, uint64_t n_remote, uint64_t skip_first, uint64_t skip_count,
                    uint64_t* n_cross);
+
+// cluster.hip
+int32_t cluster_assign(phys_world* w, const float* host_pos);
+void launch_cluster_sort(phys_world* w, unsigned blocks);
+void launch_exclusive_scan(phys_world* w, const uint32_t* in, uint32_t count, uint32_t* out);  // broadphase.hip; count % 4 == 0
+void launch_solve_cluster(phys_world* w, void* hdr, void* n, void* pt, void* tb, void* acc, uint64_t cap, float friction,
+                          const float* inertia, uint32_t stride, bool diag, long long timeout_ticks);
 
 int32_t halo_pack_bodies(phys_world* w, void* dev_out, uint64_t cap);
 int32_t halo_unpack_ghosts(phys_world* w, const void* dev_records, uint64_t n_records, uint64_t skip_first, uint64_t skip_count);

@@ -12,6 +12,8 @@
 //   colours are a pure function of (previous colouring, manifold SET).
 // Algorithmic bytes: per pair 8 + 2 x 44 (pos 12, rot 16, half 12, shape 4) = 96 B read;
 //   per manifold 100 B written (ids 8, count 4, normal 12, points 64, priority 8, colour 4).
+#include <cstdlib>
+
 #include "kernels.hpp"
 
 namespace phys {
@@ -630,6 +632,17 @@ void launch_coloring(phys_world* w) {
     const bool known = w->hint.valid && (!full || w->hint.full_rounds > 0);
     const bool small = w->hint.valid && w->hint.n_manifolds <= (uint32_t)(kSmallTrips * kColorThreads);
     bool snapshot_done = false;
+    // cluster solver this update? (decided here because it decides the ORDER of the rows: by (cluster, colour)
+    // instead of by colour). PHYS_DEBUG_CLUSTER_MIN=<manifolds> moves the threshold (measurements; same bits either way).
+    static const char* cluster_min_env = getenv("PHYS_DEBUG_CLUSTER_MIN");
+    const uint64_t cluster_min = cluster_min_env ? strtoull(cluster_min_env, nullptr, 10) : kClusterMinManifolds;
+    // worth it where contacts are dense (C5: 11 rows per body): velocities stay in LDS for many rows each. Sparse piles
+    // (the 1M-cube scene: 0.4-0.5 rows per body, contacts in the bottom layers only) leave most clusters idle and a few
+    // overloaded - they keep the dataflow / per-colour kernels, which spread rows evenly over the chip
+    const bool dense = cluster_min_env || 2ull * w->hint.n_manifolds >= 3ull * w->n_owned;
+    w->cluster_step = w->cluster_count > 0 && w->hint.valid && !small && dense && w->hint.n_manifolds >= cluster_min &&
+                      !(w->cfg.flags & PHYS_FLAG_SOLVER_PER_COLOR) && w->cfg.solver_iterations > 0 &&
+                      w->cfg.solver_iterations < 1000 && w->hint.n_colors > 0;
     if (small) {
         // one workgroup does the whole stage, snapshot of the counters included
         StepCounters* slot = snapshot_acquire(w);
@@ -668,7 +681,8 @@ void launch_coloring(phys_world* w) {
     }
     { PHYS_PROF(w, PHYS_STAGE_ROWS); hipLaunchKernelGGL(k_color_hist, dim3(nb), dim3(1024), 0, s, w->max_manifolds, w->man_color.p, w->color_block_hist.p, nb, w->counters.p); }
     { PHYS_PROF(w, PHYS_STAGE_ROWS); hipLaunchKernelGGL(k_color_offsets, dim3(1), dim3(1024), 0, s, w->color_block_hist.p, nb, w->counters.p); }
-    { PHYS_PROF(w, PHYS_STAGE_ROWS); hipLaunchKernelGGL(k_color_place, dim3(nb), dim3(1024), 0, s, w->max_manifolds, w->man_color.p, w->color_block_hist.p, nb, w->row_src.p, w->counters.p); }
+    if (w->cluster_step) launch_cluster_sort(w, blocks * (kColorThreads / 256));  // rows by (cluster of body A, colour)
+    else { PHYS_PROF(w, PHYS_STAGE_ROWS); hipLaunchKernelGGL(k_color_place, dim3(nb), dim3(1024), 0, s, w->max_manifolds, w->man_color.p, w->color_block_hist.p, nb, w->row_src.p, w->counters.p); }
     }
     {
         // colour table of this update for the next one (the slot it overwrites was read two updates ago)

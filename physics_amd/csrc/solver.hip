@@ -71,7 +71,9 @@ __global__ __launch_bounds__(256) void k_rows_build(const StepCounters* __restri
                                                     const uint32_t* __restrict__ man_color,
                                                     const unsigned long long* __restrict__ used,
                                                     int flow /* 1: k_solve_flow runs this step (tickets, no zeroed impulses) */,
-                                                    ColorTableJob table) {
+                                                    ColorTableJob table, const uint32_t* __restrict__ cluster_slot,
+                                                    const uint32_t* __restrict__ body_shared,
+                                                    uint32_t cluster_slots /* 0: not a cluster-solver step */) {
     {
         // colour table for the next update's narrow phase: built even when the solve is skipped, or the update after
         // an overflow would keep colours from a table two updates old
@@ -122,7 +124,48 @@ __global__ __launch_bounds__(256) void k_rows_build(const StepCounters* __restri
             if (flow == 2 && d == 0) ticket += 1;  // fault injection (PHYS_DEBUG_FLOW_STALL): row 0 waits for a turn that never comes
         }
         rows.hdr[d] = make_uint4(a, b, (uint32_t)sm.count, ticket);
-        rows.n[d] = make_float4(sm.n.x, sm.n.y, sm.n.z, 0.0f);
+        uint32_t info = 0;
+        if (cluster_slots) {
+            // cluster solver (cluster.hip): where each side's velocity lives. Per side: slot (13 bits) | publish (1) |
+            // mode (2): 0 own cluster, never updated by another workgroup (LDS only); 1 own cluster, shared (LDS while its
+            // tag is current, granules otherwise); 2 another cluster's body (granules only); 3 no body (ground).
+            // publish: the body's NEXT update in solve order (next colour in use at the body, cyclically) belongs to a
+            // remote row, so this update must be written to the granules for it
+            const unsigned long long bitc = 1ull << man_color[m];
+            const uint32_t sa = cluster_slot[a];
+            const uint32_t ca = sa / cluster_slots;
+            {
+                const unsigned long long rem = ((unsigned long long)body_shared[2 * (size_t)a + 1] << 32) | body_shared[2 * (size_t)a];
+                uint32_t pub = 0;
+                if (rem) {
+                    const unsigned long long ua = used[a];
+                    const unsigned long long above = ua & ~(bitc | (bitc - 1ull));
+                    const unsigned long long next = above ? (above & (~above + 1ull)) : (ua & (~ua + 1ull));  // lowest colour above, else the first
+                    pub = (rem & next) ? 1u : 0u;
+                }
+                info = (sa - ca * cluster_slots) | (pub << 13) | ((rem ? 1u : 0u) << 14);
+            }
+            uint32_t ib = 3u << 14;
+            if (has_b) {
+                const uint32_t sb = cluster_slot[b];
+                const uint32_t cb = sb / cluster_slots;
+                if (cb == ca) {
+                    const unsigned long long rem = ((unsigned long long)body_shared[2 * (size_t)b + 1] << 32) | body_shared[2 * (size_t)b];
+                    uint32_t pub = 0;
+                    if (rem) {
+                        const unsigned long long ub = used[b];
+                        const unsigned long long above = ub & ~(bitc | (bitc - 1ull));
+                        const unsigned long long next = above ? (above & (~above + 1ull)) : (ub & (~ub + 1ull));
+                        pub = (rem & next) ? 1u : 0u;
+                    }
+                    ib = (sb - cb * cluster_slots) | (pub << 13) | ((rem ? 1u : 0u) << 14);
+                } else {
+                    ib = 2u << 14;
+                }
+            }
+            info |= ib << 16;
+        }
+        rows.n[d] = make_float4(sm.n.x, sm.n.y, sm.n.z, __uint_as_float(info));
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             if (k < sm.count) {
@@ -893,8 +936,9 @@ void launch_solver(phys_world* w, float dt) {
     // PHYS_DEBUG_FLOW_MAX=<manifolds>: move the dataflow / per-colour crossover (measurements only; same bits either way)
     static const char* flow_max_env = getenv("PHYS_DEBUG_FLOW_MAX");
     const uint64_t flow_max = flow_max_env ? strtoull(flow_max_env, nullptr, 10) : kFlowMaxManifolds;
-    const bool flow = w->flow_vel.p && h.valid && m_hint <= flow_max && w->cfg.solver_iterations > 0 &&
-                      w->cfg.solver_iterations < 1000;
+    const bool cluster = w->cluster_step;  // decided by launch_coloring: this update's rows are in (cluster, colour) order
+    const bool flow = cluster || (w->flow_vel.p && h.valid && m_hint <= flow_max && w->cfg.solver_iterations > 0 &&
+                                  w->cfg.solver_iterations < 1000);
     // fault injection for tests/test_gpu_full_size.py: one row gets a ticket nobody will ever publish, so the bounded
     // spin of the dataflow kernels must give up, flag the step (overflow bit 4) and let the launch end
     static const bool stall = getenv("PHYS_DEBUG_FLOW_STALL") != nullptr;
@@ -915,16 +959,23 @@ void launch_solver(phys_world* w, float dt) {
       if (diag)
           hipLaunchKernelGGL(k_rows_build<true>, grid_for_count(m_hint), tb, 0, s, w->counters.p, rows, sp, w->row_src.p, w->man_a.p, w->man_b.p, w->man_count.p,
                              w->man_normal.p, w->man_points.p, w->pos.p, w->vel.p, inertia, stride, w->man_color.p,
-                             w->color_state.p, flow ? (stall ? 2 : 1) : 0, table);
+                             w->color_state.p, flow ? (stall ? 2 : 1) : 0, table, w->cluster_slot.p, w->body_shared.p,
+                             w->cluster_step ? w->cluster_slots : 0u);
       else
           hipLaunchKernelGGL(k_rows_build<false>, grid_for_count(m_hint), tb, 0, s, w->counters.p, rows, sp, w->row_src.p, w->man_a.p, w->man_b.p, w->man_count.p,
                              w->man_normal.p, w->man_points.p, w->pos.p, w->vel.p, inertia, stride, w->man_color.p,
-                             w->color_state.p, flow ? (stall ? 2 : 1) : 0, table); }
+                             w->color_state.p, flow ? (stall ? 2 : 1) : 0, table, w->cluster_slot.p, w->body_shared.p,
+                             w->cluster_step ? w->cluster_slots : 0u); }
     if (flow) {
         if (++w->flow_epoch > 0xFFFFu) {  // tags would repeat: forget every old one
             (void)hipMemsetAsync(w->flow_vel.p, 0, 8 * w->n * sizeof(float), s);
             (void)hipMemsetAsync(w->row_acc.p, 0, 16 * cap * sizeof(float), s);
             w->flow_epoch = 1;
+        }
+        if (cluster) {
+            PHYS_PROF(w, PHYS_STAGE_SOLVE_CLUSTER);
+            launch_solve_cluster(w, rows.hdr, rows.n, rows.pt, rows.tb, rows.acc, cap, sp.friction, inertia, stride, diag, timeout_ticks);
+            return;
         }
         // about one wave per SIMD or less: waiting waves must not crowd out the ones that can run
         const bool quad = m_hint <= kFlowQuadMaxManifolds;  // four lanes per manifold while the hop latency is everything

@@ -16,6 +16,9 @@
 namespace phys {
 
 constexpr int kMaxColors = 64;  // == PHYS_MAX_COLORS of include/spec/contact_solve.h
+constexpr uint64_t kClusterMinBodies = 32768;  // below: the dataflow kernels win anyway (few launches' worth of rows)
+constexpr uint64_t kClusterMinManifolds = 300000;  // fewer rows: the single-launch dataflow kernel (measured crossover)
+constexpr uint32_t kClusterMaxSlots = 4608;    // bodies per cluster whose {v, w} fit one CU's LDS (32 B each: 144 KiB; 13-bit slot field)
 
 void set_error(const std::string& msg);
 const char* get_error();
@@ -236,6 +239,14 @@ struct phys_world {
     // 16-byte granules {x, y, z, tag} (the tag says WHICH update of that body the data is: the data is its own
     // ready flag)
     phys::DevBuf<float> flow_vel;    // 8 per body: {v.xyz, tag} {w.xyz, tag}; null = per-colour launches only
+    // cluster solver (cluster.hip): spatial clusters fixed at phys_set_bodies, rows sorted by (cluster, colour) per step
+    uint32_t cluster_count = 0, cluster_slots = 0;  // 0 clusters: not available for this scene
+    bool cluster_step = false;                      // this update's rows are in (cluster, colour) order
+    phys::DevBuf<uint32_t> cluster_slot;   // body -> cluster * slots + slot
+    phys::DevBuf<uint32_t> cluster_body;   // cluster * slots + slot -> body (0xFFFFFFFF: empty)
+    phys::DevBuf<uint32_t> body_shared;    // 2 per body: 64-bit mask of the colours in which ANOTHER cluster's row updates it
+    phys::DevBuf<uint32_t> seg_count, seg_start;  // rows per (cluster, colour) and their exclusive scan
+    phys::DevBuf<uint32_t> man_rank;       // manifold -> arrival rank inside its segment
     uint32_t flow_epoch = 0;         // solves since the buffers were cleared (upper half of every tag)
     // multi-GPU halo
     phys::DevBuf<uint32_t> cross_pairs;

@@ -71,7 +71,7 @@ pub struct phys_comm {
     _private: [u8; 0],
 }
 
-pub const PHYS_STAGE_COUNT: usize = 13;
+pub const PHYS_STAGE_COUNT: usize = 14;
 pub const PHYS_COMM_ID_BYTES: usize = 128;
 pub const PHYS_HALO_BODY_RECORD_BYTES: usize = 96;
 

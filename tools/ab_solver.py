@@ -14,17 +14,25 @@ import sys
 import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+NC = {"PHYS_DEBUG_NO_CLUSTER": "1"}
 VARIANTS = {
-    "lane": {"PHYS_DEBUG_COLOR_KERNEL": "lane", "PHYS_DEBUG_FLOW_MAX": "0"},
-    "quad": {"PHYS_DEBUG_COLOR_KERNEL": "quad", "PHYS_DEBUG_FLOW_MAX": "0"},
-    "auto": {"PHYS_DEBUG_FLOW_MAX": "0"},
-    "flow": {"PHYS_DEBUG_FLOW_MAX": "100000000"},
+    "lane": dict(NC, PHYS_DEBUG_COLOR_KERNEL="lane", PHYS_DEBUG_FLOW_MAX="0"),
+    "quad": dict(NC, PHYS_DEBUG_COLOR_KERNEL="quad", PHYS_DEBUG_FLOW_MAX="0"),
+    "auto": dict(NC, PHYS_DEBUG_FLOW_MAX="0"),
+    "flow": dict(NC, PHYS_DEBUG_FLOW_MAX="100000000"),
+    "cluster": {"PHYS_DEBUG_CLUSTER_MIN": "0"},   # the cluster solver whenever the scene has clusters (>= 32768 bodies)
+    "nocluster": dict(NC),
+    "cluster1": {"PHYS_DEBUG_CLUSTER_MIN": "0", "PHYS_DEBUG_CLUSTERS_PER_CU": "1"},
+    "cluster3": {"PHYS_DEBUG_CLUSTER_MIN": "0", "PHYS_DEBUG_CLUSTERS_PER_CU": "3"},
+    "cl_nogran": {"PHYS_DEBUG_CLUSTER_MIN": "0", "PHYS_DEBUG_ABLATE": "8"},    # timing only: shared bodies treated as local
+    "cl_nocompute": {"PHYS_DEBUG_CLUSTER_MIN": "0", "PHYS_DEBUG_ABLATE": "2"},  # timing only
+    "cl_bare": {"PHYS_DEBUG_CLUSTER_MIN": "0", "PHYS_DEBUG_ABLATE": "10"},      # timing only: neither
     "default": {},
     # timing diagnosis of the one-lane per-colour kernel (results are WRONG by construction: hashes differ)
-    "nogather": {"PHYS_DEBUG_COLOR_KERNEL": "lane", "PHYS_DEBUG_FLOW_MAX": "0", "PHYS_DEBUG_ABLATE": "1"},
-    "nocompute": {"PHYS_DEBUG_COLOR_KERNEL": "lane", "PHYS_DEBUG_FLOW_MAX": "0", "PHYS_DEBUG_ABLATE": "2"},
-    "nostore": {"PHYS_DEBUG_COLOR_KERNEL": "lane", "PHYS_DEBUG_FLOW_MAX": "0", "PHYS_DEBUG_ABLATE": "4"},
-    "loadonly": {"PHYS_DEBUG_COLOR_KERNEL": "lane", "PHYS_DEBUG_FLOW_MAX": "0", "PHYS_DEBUG_ABLATE": "7"},
+    "nogather": dict(NC, PHYS_DEBUG_COLOR_KERNEL="lane", PHYS_DEBUG_FLOW_MAX="0", PHYS_DEBUG_ABLATE="1"),
+    "nocompute": dict(NC, PHYS_DEBUG_COLOR_KERNEL="lane", PHYS_DEBUG_FLOW_MAX="0", PHYS_DEBUG_ABLATE="2"),
+    "nostore": dict(NC, PHYS_DEBUG_COLOR_KERNEL="lane", PHYS_DEBUG_FLOW_MAX="0", PHYS_DEBUG_ABLATE="4"),
+    "loadonly": dict(NC, PHYS_DEBUG_COLOR_KERNEL="lane", PHYS_DEBUG_FLOW_MAX="0", PHYS_DEBUG_ABLATE="7"),
 }
 
 
