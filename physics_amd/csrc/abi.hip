@@ -159,12 +159,12 @@ int32_t phys_destroy(phys_world* w) {
     if (w->stream) (void)hipStreamSynchronize(w->stream);
     DevBuf<float>* fb[] = {&w->pos, &w->rot, &w->vel, &w->force, &w->torque, &w->inv_inertia_diag,
                            &w->inv_inertia, &w->half_extent, &w->aabb, &w->cg_x, &w->cg_r, &w->cg_p, &w->cg_ap,
-                           &w->cg_rhs, &w->cg_c, &w->cg_scratch, &w->man_normal, &w->man_points, &w->row_n,
+                           &w->cg_rhs, &w->cg_c, &w->cg_scratch, &w->man_geo, &w->row_n,
                            &w->row_pt, &w->row_tb, &w->row_acc, &w->row_all, &w->flow_vel, &w->sorted_box, &w->slot_box};
     for (auto* b : fb) b->free();
     DevBuf<uint32_t>* ub[] = {&w->shape, &w->global_id, &w->cg_status, &w->bucket_of, &w->bucket_count,
                               &w->bucket_start, &w->bucket_cursor, &w->sorted_ids, &w->slot_ids, &w->grid_ovf, &w->scan_block_sums, &w->pairs,
-                              &w->man_a, &w->man_b, &w->man_count, &w->man_color, &w->row_hdr, &w->halo_block_counts,
+                              &w->man_a, &w->man_b, &w->man_color, &w->row_hdr, &w->halo_block_counts,
                               &w->cluster_slot, &w->cluster_body, &w->body_shared, &w->seg_count, &w->seg_start, &w->man_rank,
                               &w->row_src, &w->cross_pairs, &w->color_block_hist, &w->cg_cols};
     for (auto* b : ub) b->free();
@@ -521,11 +521,16 @@ int32_t phys_get_manifolds(phys_world* w, uint32_t* ids_out, uint32_t* counts_ou
     // read back in storage order, sort by (a, b) on the host (a read-out convenience, not the hot path)
     std::vector<uint32_t> a(m), b(m), c(m);
     std::vector<float> nrm(3 * m), pts(16 * m);
-    PHYS_HIP_TRY(hipMemcpy(a.data(), w->man_a.p, 4 * m, hipMemcpyDeviceToHost));
-    PHYS_HIP_TRY(hipMemcpy(b.data(), w->man_b.p, 4 * m, hipMemcpyDeviceToHost));
-    PHYS_HIP_TRY(hipMemcpy(c.data(), w->man_count.p, 4 * m, hipMemcpyDeviceToHost));
-    PHYS_HIP_TRY(hipMemcpy(nrm.data(), w->man_normal.p, 12 * m, hipMemcpyDeviceToHost));
-    PHYS_HIP_TRY(hipMemcpy(pts.data(), w->man_points.p, 64 * m, hipMemcpyDeviceToHost));
+    {
+        std::vector<float> geo(32 * m);  // 128-byte records: {a, b, count, -} {normal, -} 4 x {point, depth} + 32 spare bytes
+        PHYS_HIP_TRY(hipMemcpy(geo.data(), w->man_geo.p, 128 * m, hipMemcpyDeviceToHost));
+        for (uint64_t k = 0; k < m; ++k) {
+            const float* g = &geo[32 * k];
+            std::memcpy(&a[k], g, 4); std::memcpy(&b[k], g + 1, 4); std::memcpy(&c[k], g + 2, 4);
+            std::memcpy(&nrm[3 * k], g + 4, 12);
+            std::memcpy(&pts[16 * k], g + 8, 64);
+        }
+    }
     std::vector<uint64_t> order(m);
     for (uint64_t k = 0; k < m; ++k) order[k] = k;
     std::sort(order.begin(), order.end(), [&](uint64_t x, uint64_t y) { return a[x] < a[y] || (a[x] == a[y] && b[x] < b[y]); });

@@ -552,9 +552,9 @@ int32_t collision_alloc(phys_world* w) {
     PHYS_HIP_TRY(w->pairs.resize(2 * w->max_pairs));
     if (!(w->cfg.flags & PHYS_FLAG_BROADPHASE_ONLY)) {
         const uint64_t M = w->max_manifolds;
-        PHYS_HIP_TRY(w->man_a.resize(M)); PHYS_HIP_TRY(w->man_b.resize(M)); PHYS_HIP_TRY(w->man_count.resize(M));
+        PHYS_HIP_TRY(w->man_a.resize(M)); PHYS_HIP_TRY(w->man_b.resize(M));
         PHYS_HIP_TRY(w->man_color.resize(M));
-        PHYS_HIP_TRY(w->man_normal.resize(3 * M)); PHYS_HIP_TRY(w->man_points.resize(16 * M));
+        PHYS_HIP_TRY(w->man_geo.resize(32 * M));
         PHYS_HIP_TRY(w->man_prio.resize(M));
         PHYS_HIP_TRY(w->row_src.resize(M));
         {

@@ -32,6 +32,7 @@ namespace phys {
 // occupancy asked for: three workgroups per CU (3 waves per SIMD, <= 168 VGPRs; at 128 the kernel spills 2) with diagonal
 // tensors, two otherwise. Measured on C5, same bits: 1 per CU 3.48 ms, 2 per CU 2.70, 3 per CU 2.20
 constexpr int kClusterPerCuDiag = 3, kClusterPerCuFull = 2;
+constexpr int kClusterPairPerCuDecl = 4;  // == kClusterPairPerCu of k_solve_cluster_pair below
 
 // per-row side info packed into row_n.w (as bits): slot (16) | mode (2) per side
 //   mode 0: own cluster, never shared -> LDS only          1: own cluster, shared -> LDS while its tag is current, else granule
@@ -59,7 +60,11 @@ int32_t cluster_assign(phys_world* w, const float* pos /* host, 3 * n_owned */) 
     // solve); an eighth of the chip to spare: EVERY workgroup must be resident (the kernel's occupancy bound admits
     // kClusterPerCu* of them per CU; a workgroup that found no room would be waited for until the time-out)
     static const char* per_cu_env = getenv("PHYS_DEBUG_CLUSTERS_PER_CU");
-    const int per_cu_max = w->all_diag_inertia ? kClusterPerCuDiag : kClusterPerCuFull;
+    // two lanes per row (k_solve_cluster_pair, four workgroups per CU) with diagonal tensors; PHYS_DEBUG_CLUSTER_KERNEL=lane
+    // keeps the one-lane kernel (A/B measurements; same bits)
+    static const char* kernel_env = getenv("PHYS_DEBUG_CLUSTER_KERNEL");
+    w->cluster_pair = w->all_diag_inertia && !(kernel_env && kernel_env[0] == 'l');
+    const int per_cu_max = w->cluster_pair ? kClusterPairPerCuDecl : (w->all_diag_inertia ? kClusterPerCuDiag : kClusterPerCuFull);
     const int per_cu = per_cu_env ? std::min(per_cu_max, std::max(1, atoi(per_cu_env))) : per_cu_max;
     const uint32_t max_clusters = (uint32_t)std::max(8, per_cu * (cus - cus / 8));
     uint32_t slots = (uint32_t)((n + max_clusters - 1) / max_clusters);
@@ -367,6 +372,218 @@ __global__ __launch_bounds__(kClusterThreads, DIAG ? kClusterPerCuDiag : kCluste
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// The same solver with TWO LANES PER ROW: the even lane of a pair owns body A, the odd lane body B. At three
+// workgroups per CU the one-lane kernel is bound by the latency of a colour step - row fetch, then 12 sequential rows
+// of ~100 instructions each on lanes of which only half hold a row (C5: ~130 rows per step for 256 lanes). Here a
+// lane fetches its own side's planes, makes its own Jacobian column (r x dir, I^-1 (r x dir)) and its own half of the
+// relative velocity (dir.v + a.w); the halves meet through one DPP exchange inside the pair and are combined in the
+// order of the spec, ub - ua; both lanes then make the same scalar update and apply it to their own body. Half the
+// chain per lane, every lane busy, ~100 VGPRs (four workgroups per CU). Same arithmetic, same bits.
+constexpr int kPairXor1 = 0xB1;  // quad_perm [1, 0, 3, 2]
+__device__ __forceinline__ float pair_swap(float v) {
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), kPairXor1, 0xF, 0xF, true));
+}
+__device__ __forceinline__ uint32_t pair_swap_u(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, kPairXor1, 0xF, 0xF, true);
+}
+
+constexpr int kClusterPairPerCu = kClusterPairPerCuDecl;
+template <bool DIAG>
+__global__ __launch_bounds__(kClusterThreads, kClusterPairPerCu) void k_solve_cluster_pair(
+    StepCounters* ctr, uint32_t iterations, uint32_t epoch, ClusterRowArrays rows, float friction,
+    const float* __restrict__ inv_inertia, uint32_t inertia_stride, float* vel, float* flow_vel, uint32_t n_bodies,
+    const uint32_t* __restrict__ cluster_body, const uint32_t* __restrict__ body_shared, const uint32_t* __restrict__ seg_start,
+    uint32_t slots, long long timeout_ticks) {
+    extern __shared__ __attribute__((aligned(16))) float4 s_lds2[];
+    float4* s_vel = s_lds2;
+    uint32_t* s_seg = reinterpret_cast<uint32_t*>(s_lds2 + 2 * (size_t)slots);
+    if (ctr->overflow) return;
+    const uint32_t cluster = blockIdx.x;
+    const uint32_t n_colors = ctr->n_colors;
+    const uint32_t etag = epoch << 16;
+    const uint32_t cap = (uint32_t)rows.cap;
+    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(flow_vel, 0, n_bodies * 32u, 0x00020000);
+    for (uint32_t sl = threadIdx.x; sl < slots; sl += kClusterThreads) {
+        const uint32_t body = cluster_body[(size_t)cluster * slots + sl];
+        float4 a = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(etag)), b = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (body != 0xFFFFFFFFu) {
+            const float4 v0 = reinterpret_cast<const float4*>(vel)[2 * (size_t)body];
+            const float4 v1 = reinterpret_cast<const float4*>(vel)[2 * (size_t)body + 1];
+            a = make_float4(v0.x, v0.y, v0.z, __uint_as_float(etag));
+            b = make_float4(v1.x, v1.y, v1.z, v0.w);
+        }
+        s_vel[2 * sl] = a;
+        s_vel[2 * sl + 1] = b;
+    }
+    if (threadIdx.x <= (uint32_t)PHYS_MAX_COLORS) s_seg[threadIdx.x] = seg_start[(size_t)cluster * PHYS_MAX_COLORS + threadIdx.x];
+    __syncthreads();
+    const long long t_start = wall_clock64();
+    const bool side_b = (threadIdx.x & 1u) != 0u;
+    const uint32_t pair = threadIdx.x >> 1;
+    constexpr uint32_t kPairs = kClusterThreads / 2;
+    const v3 zero = v3_make(0.0f, 0.0f, 0.0f);
+    bool dead = false;
+    const uint32_t steps = iterations * n_colors;
+    uint32_t it = 0, col = 0;
+    for (uint32_t step = 0; step < steps; ++step) {
+        const bool last_it = it + 1 == iterations;
+        const uint32_t seg_lo = s_seg[col], seg_hi = s_seg[col + 1];
+        // pass count is the same for every lane of the workgroup (the DPP exchanges need both lanes of a pair, and a pair
+        // whose row index falls beyond the segment simply carries zeros)
+        for (uint32_t base = seg_lo; base < seg_hi; base += kPairs) {
+            const uint32_t d = base + pair;
+            const bool live = d < seg_hi;
+            const uint32_t dd = live ? d : seg_lo;  // a readable row for idle pairs (nothing of it is used)
+            // ---- this side's share of the row
+            const uint4 h = rows.hdr[dd];
+            const float4 nn = rows.n[dd];
+            const float4 t01 = rows.tb[dd], t23r = rows.tb[cap + dd];
+            float4 pr[4], ac[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                pr[k] = rows.pt[(size_t)(2 * k + (side_b ? 1 : 0)) * cap + dd];  // A: {rA, normal mass}  B: {rB, tangent mass 0}
+                ac[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                if (it != 0u) ac[k] = rows.acc[(size_t)k * cap + dd];  // written by this pair one iteration ago
+            }
+            const uint32_t count = live ? h.z : 0u;
+            const bool has_b = h.y != PHYS_GROUND_ID;
+            const uint32_t info = __float_as_uint(nn.w) >> (side_b ? 16 : 0);
+            const uint32_t slot = info & 0x1FFFu, mode = live ? ((info >> 14) & 3u) : 3u;
+            const bool pub = (info >> 13) & 1u;
+            const uint32_t body = side_b ? h.y : h.x;
+            const uint32_t tk = side_b ? (h.w >> 16) : h.w;
+            const uint32_t rank = tk & 0xFFu, deg = (tk >> 8) & 0xFFu;
+            const uint32_t ticket = it * deg + rank;
+            const bool final_update = last_it && rank + 1 == deg;
+            v3 dir[3];
+            dir[2] = v3_make(nn.x, nn.y, nn.z);
+            tangent_basis(dir[2], &dir[0], &dir[1]);
+            // masses and bias of every point, on both lanes: this side's plane carries one of the two packed masses
+            float nm[4], tm0[4], tm1[4], bias[4], pn[4], pt0[4], pt1[4];
+            v3 r[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float mine = pr[k].w, other = pair_swap(pr[k].w);
+                nm[k] = side_b ? other : mine;
+                tm0[k] = side_b ? mine : other;
+                const float4 t = k < 2 ? t01 : t23r;
+                tm1[k] = (k & 1) ? t.z : t.x;
+                bias[k] = (k & 1) ? t.w : t.y;
+                pn[k] = ac[k].x; pt0[k] = ac[k].y; pt1[k] = ac[k].z;
+                r[k] = v3_make(pr[k].x, pr[k].y, pr[k].z);
+            }
+            // ---- this side's body
+            v3 v = zero, w = zero;
+            float inv_m = 0.0f, mass = 0.0f;
+            bool need = false;
+            if (mode == 0u || mode == 1u) {
+                const float4 la = s_vel[2 * slot], lb = s_vel[2 * slot + 1];
+                v = v3_make(la.x, la.y, la.z); w = v3_make(lb.x, lb.y, lb.z); inv_m = lb.w;
+                if (mode == 1u) {
+                    need = __float_as_uint(la.w) != (etag | ticket);  // a remote row made the update before this one
+                    if (final_update) mass = vel[8 * (size_t)body + 7];
+                }
+            } else if (mode == 2u) {
+                const BodyVel B0 = ld_vel(vel, body);  // the state itself for ticket 0, the masses always
+                v = B0.v; w = B0.w; inv_m = B0.inv_mass; mass = B0.mass;
+                need = ticket != 0u;
+            }
+            uint32_t sweeps = 0;
+            while (need) {
+                const u32x4c g0 = ld_gran(rv, body * 32u), g1 = ld_gran(rv, body * 32u + 16u);
+                if (g0.w == (etag | ticket) && g1.w == (etag | ticket)) {
+                    v = v3_make(__uint_as_float(g0.x), __uint_as_float(g0.y), __uint_as_float(g0.z));
+                    w = v3_make(__uint_as_float(g1.x), __uint_as_float(g1.y), __uint_as_float(g1.z));
+                    need = false;
+                } else {
+                    __builtin_amdgcn_s_sleep(8);
+                    if ((++sweeps & 63u) == 0u) {
+                        const bool gone = (wall_clock64() - t_start > timeout_ticks) ||
+                                          (__hip_atomic_load(&ctr->overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 16u);
+                        if (gone) { flag_overflow(ctr, 16u); dead = true; need = false; }
+                    }
+                }
+            }
+            // a pair acts only when both of its lanes have their body; every lane reaches the exchanges below
+            const uint32_t pair_dead = (dead ? 1u : 0u) | pair_swap_u(dead ? 1u : 0u);
+            const bool has_body = mode != 3u;
+            m33 I;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) I.m[k] = 0.0f;
+            if (has_body) I = ld_inertia_c<DIAG>(inv_inertia, body * inertia_stride);
+            v3 lin[3];  // lA / lB of the spec: dir * inverse mass (zero for a side without a body)
+#pragma unroll
+            for (int t = 0; t < 3; ++t) lin[t] = has_body ? v3_scale(dir[t], inv_m) : zero;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (k < (int)count) {  // the same for both lanes of the pair
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) {
+                        // jac_row_make: a = r x dir, m = I a (zero for a side without a body)
+                        const v3 a = has_body ? v3_cross(r[k], dir[t]) : zero;
+                        const v3 mI = has_body ? m33_mul_v3(&I, a) : zero;
+                        // row_velocity: ub - ua with ua = dir.vA + aA.wA, ub = has_b ? dir.vB + aB.wB : 0
+                        const float mine = has_body ? v3_dot(dir[t], v) + v3_dot(a, w) : 0.0f;
+                        const float other = pair_swap(mine);
+                        const float vrel = side_b ? mine - other : other - mine;
+                        float lambda;
+                        if (t < 2) {  // solve_row_dir, friction
+                            const float tm = t == 0 ? tm0[k] : tm1[k];
+                            float& accu = t == 0 ? pt0[k] : pt1[k];
+                            lambda = -tm * vrel;
+                            const float maxf = friction * pn[k];
+                            const float old = accu;
+                            const float np = det_maxf(-maxf, det_minf(old + lambda, maxf));
+                            lambda = np - old;
+                            accu = np;
+                        } else {      // normal
+                            lambda = nm[k] * (bias[k] - vrel);
+                            const float old = pn[k];
+                            const float np = det_maxf(old + lambda, 0.0f);
+                            lambda = np - old;
+                            pn[k] = np;
+                        }
+                        // row_apply: A subtracts, B adds
+                        if (has_body) {
+                            if (side_b) { v = v3_add(v, v3_scale(lin[t], lambda)); w = v3_add(w, v3_scale(mI, lambda)); }
+                            else        { v = v3_sub(v, v3_scale(lin[t], lambda)); w = v3_sub(w, v3_scale(mI, lambda)); }
+                        }
+                    }
+                }
+            }
+            // ---- write back
+            if (live && !pair_dead) {
+                if (mode == 0u || mode == 1u) {
+                    s_vel[2 * slot] = make_float4(v.x, v.y, v.z, __uint_as_float(etag | (ticket + 1u)));
+                    s_vel[2 * slot + 1] = make_float4(w.x, w.y, w.z, inv_m);
+                }
+                if (mode == 1u || mode == 2u) {
+                    if (final_update) { BodyVel o; o.v = v; o.inv_mass = inv_m; o.w = w; o.mass = mass; st_vel(vel, body, o); }
+                    else if (mode == 2u || pub) { st_gran(rv, body * 32u, v, etag | (ticket + 1u)); st_gran(rv, body * 32u + 16u, w, etag | (ticket + 1u)); }
+                }
+                if (!last_it) {  // the A lane keeps the impulses of points 0 and 1, the B lane those of 2 and 3
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (k < (int)count && ((k >> 1) == (side_b ? 1 : 0)))
+                            rows.acc[(size_t)k * cap + d] = make_float4(pn[k], pt0[k], pt1[k], 0.0f);
+                }
+            }
+        }
+        __syncthreads();  // LDS velocities of this colour are in place before the next colour reads them
+        if (++col == n_colors) { col = 0u; ++it; }
+    }
+    for (uint32_t sl = threadIdx.x; sl < slots; sl += kClusterThreads) {
+        const uint32_t body = cluster_body[(size_t)cluster * slots + sl];
+        if (body == 0xFFFFFFFFu || (body_shared[2 * (size_t)body] | body_shared[2 * (size_t)body + 1])) continue;
+        const float4 a = s_vel[2 * sl], b = s_vel[2 * sl + 1];
+        float4* out = reinterpret_cast<float4*>(vel) + 2 * (size_t)body;
+        const float mass = out[1].w;
+        out[0] = make_float4(a.x, a.y, a.z, b.w);
+        out[1] = make_float4(b.x, b.y, b.z, mass);
+    }
+}
+
 void launch_solve_cluster(phys_world* w, void* hdr, void* nrm, void* pt, void* tb, void* acc, uint64_t cap, float friction,
                           const float* inertia, uint32_t stride, bool diag, long long timeout_ticks) {
     static const uint32_t ablate = getenv("PHYS_DEBUG_ABLATE") ? (uint32_t)atoi(getenv("PHYS_DEBUG_ABLATE")) : 0u;
@@ -381,6 +598,18 @@ void launch_solve_cluster(phys_world* w, void* hdr, void* nrm, void* pt, void* t
         attr_set[diag ? 1 : 0] = true;
     }
     const dim3 g(w->cluster_count), b(kClusterThreads);
+    if (w->cluster_pair) {
+        static bool pair_attr = false;
+        if (!pair_attr) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_solve_cluster_pair<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipGetLastError();
+            pair_attr = true;
+        }
+        hipLaunchKernelGGL(k_solve_cluster_pair<true>, g, b, lds, w->stream, w->counters.p, w->cfg.solver_iterations, w->flow_epoch, rows,
+                           friction, inertia, stride, w->vel.p, w->flow_vel.p, (uint32_t)w->n, w->cluster_body.p, w->body_shared.p,
+                           w->seg_start.p, w->cluster_slots, timeout_ticks);
+        return;
+    }
     if (diag)
         hipLaunchKernelGGL(k_solve_cluster<true>, g, b, lds, w->stream, w->counters.p, w->cfg.solver_iterations, w->flow_epoch, rows, friction,
                            inertia, stride, w->vel.p, w->flow_vel.p, (uint32_t)w->n, w->cluster_body.p, w->body_shared.p, w->seg_start.p,

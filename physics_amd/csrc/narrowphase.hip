@@ -37,8 +37,8 @@ __global__ __launch_bounds__(kNpThreads) void k_narrowphase(
     uint64_t max_pairs, const float* __restrict__ pos, const float* __restrict__ rot,
     const float* __restrict__ half_extent, const uint32_t* __restrict__ shape, float margin, float ground,
     uint64_t max_manifolds, uint32_t* __restrict__ man_a, uint32_t* __restrict__ man_b,
-    uint32_t* __restrict__ man_count, uint32_t* __restrict__ man_color, float* __restrict__ man_normal,
-    float* __restrict__ man_points, uint64_t* __restrict__ man_prio, unsigned long long* __restrict__ used,
+    uint32_t* __restrict__ man_color, float* __restrict__ man_geo /* 32 floats per manifold */,
+    uint64_t* __restrict__ man_prio, unsigned long long* __restrict__ used,
     unsigned long long* __restrict__ top0, const unsigned long long* __restrict__ cache_keys,
     const uint32_t* __restrict__ cache_cols, uint32_t cache_mask /* 0 = keep nothing this update */,
     StepCounters* __restrict__ ctr) {
@@ -112,7 +112,6 @@ __global__ __launch_bounds__(kNpThreads) void k_narrowphase(
             if (slot < max_manifolds) {
                 man_a[slot] = a;
                 man_b[slot] = b;
-                man_count[slot] = (uint32_t)m.count;
                 const unsigned long long prio = color_priority(a, b);
                 man_prio[slot] = prio;
                 // persistent colouring (contact_solve.h): a manifold that existed in the previous update keeps
@@ -143,10 +142,11 @@ __global__ __launch_bounds__(kNpThreads) void k_narrowphase(
                     atomicMax(&top0[a], prio);
                     if (b != PHYS_GROUND_ID) atomicMax(&top0[b], prio);
                 }
-                st3(man_normal, (uint32_t)slot, m.normal);
-                float4* o = reinterpret_cast<float4*>(man_points) + 4 * slot;
+                float4* o = reinterpret_cast<float4*>(man_geo) + 8 * slot;  // one 128-byte line per manifold, 96 bytes used
+                o[0] = make_float4(__uint_as_float(a), __uint_as_float(b), __uint_as_float((uint32_t)m.count), 0.0f);
+                o[1] = make_float4(m.normal.x, m.normal.y, m.normal.z, 0.0f);
 #pragma unroll
-                for (int k = 0; k < 4; ++k) o[k] = make_float4(m.pt[k].x, m.pt[k].y, m.pt[k].z, m.depth[k]);
+                for (int k = 0; k < 4; ++k) o[2 + k] = make_float4(m.pt[k].x, m.pt[k].y, m.pt[k].z, m.depth[k]);
             }
         }
         const unsigned long long umask = __ballot(uncolored);
@@ -592,8 +592,8 @@ void launch_narrowphase(phys_world* w) {
         if (blocks > 256 * 16) blocks = 256 * 16;                                                                      \
         hipLaunchKernelGGL((k_narrowphase<T>), dim3((unsigned)blocks), dim3(T), 0, w->stream, n_ground, n_owned, w->pairs.p, \
                            w->max_pairs, w->pos.p, w->rot.p, w->half_extent.p, w->shape.p, w->cfg.contact_margin,      \
-                           w->cfg.ground_height, w->max_manifolds, w->man_a.p, w->man_b.p, w->man_count.p,             \
-                           w->man_color.p, w->man_normal.p, w->man_points.p, w->man_prio.p, w->color_state.p,          \
+                           w->cfg.ground_height, w->max_manifolds, w->man_a.p, w->man_b.p,                             \
+                           w->man_color.p, w->man_geo.p, w->man_prio.p, w->color_state.p,                              \
                            w->color_state.p + n, (const unsigned long long*)w->ctab_keys[prev_tab].p,                  \
                            w->ctab_cols[prev_tab].p, cache_mask, w->counters.p);                                       \
     } while (0)

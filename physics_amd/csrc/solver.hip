@@ -62,10 +62,8 @@ struct RowArrays {
 template <bool DIAG>
 __global__ __launch_bounds__(256) void k_rows_build(const StepCounters* __restrict__ ctr, RowArrays rows, solve_params_t sp,
                                                     const uint32_t* __restrict__ row_src,
-                                                    const uint32_t* __restrict__ man_a, const uint32_t* __restrict__ man_b,
-                                                    const uint32_t* __restrict__ man_count,
-                                                    const float* __restrict__ man_normal,
-                                                    const float* __restrict__ man_points, const float* __restrict__ pos,
+                                                    const float* __restrict__ man_geo /* 128-byte records */,
+                                                    const float* __restrict__ pos,
                                                     const float* __restrict__ vel,
                                                     const float* __restrict__ inv_inertia, uint32_t inertia_stride,
                                                     const uint32_t* __restrict__ man_color,
@@ -88,13 +86,14 @@ __global__ __launch_bounds__(256) void k_rows_build(const StepCounters* __restri
     for (uint32_t d = blockIdx.x * blockDim.x + threadIdx.x; d < M; d += gridDim.x * blockDim.x) {
         const uint32_t m = row_src[d];
         manifold_t g;
-        const uint32_t a = man_a[m], b = man_b[m];
-        g.count = (int)man_count[m];
-        g.normal = ld3(man_normal, m);
-        const float4* pp = reinterpret_cast<const float4*>(man_points) + 4 * (size_t)m;
+        const float4* rec = reinterpret_cast<const float4*>(man_geo) + 8 * (size_t)m;  // ONE line through the row permutation
+        const float4 r0 = rec[0], r1 = rec[1];
+        const uint32_t a = __float_as_uint(r0.x), b = __float_as_uint(r0.y);
+        g.count = (int)__float_as_uint(r0.z);
+        g.normal = v3_make(r1.x, r1.y, r1.z);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const float4 p = pp[k];
+            const float4 p = rec[2 + k];
             g.pt[k] = v3_make(p.x, p.y, p.z);
             g.depth[k] = p.w;
         }
@@ -957,13 +956,13 @@ void launch_solver(phys_world* w, float dt) {
     }
     { PHYS_PROF(w, PHYS_STAGE_ROWS);
       if (diag)
-          hipLaunchKernelGGL(k_rows_build<true>, grid_for_count(m_hint), tb, 0, s, w->counters.p, rows, sp, w->row_src.p, w->man_a.p, w->man_b.p, w->man_count.p,
-                             w->man_normal.p, w->man_points.p, w->pos.p, w->vel.p, inertia, stride, w->man_color.p,
+          hipLaunchKernelGGL(k_rows_build<true>, grid_for_count(m_hint), tb, 0, s, w->counters.p, rows, sp, w->row_src.p, w->man_geo.p,
+                             w->pos.p, w->vel.p, inertia, stride, w->man_color.p,
                              w->color_state.p, flow ? (stall ? 2 : 1) : 0, table, w->cluster_slot.p, w->body_shared.p,
                              w->cluster_step ? w->cluster_slots : 0u);
       else
-          hipLaunchKernelGGL(k_rows_build<false>, grid_for_count(m_hint), tb, 0, s, w->counters.p, rows, sp, w->row_src.p, w->man_a.p, w->man_b.p, w->man_count.p,
-                             w->man_normal.p, w->man_points.p, w->pos.p, w->vel.p, inertia, stride, w->man_color.p,
+          hipLaunchKernelGGL(k_rows_build<false>, grid_for_count(m_hint), tb, 0, s, w->counters.p, rows, sp, w->row_src.p, w->man_geo.p,
+                             w->pos.p, w->vel.p, inertia, stride, w->man_color.p,
                              w->color_state.p, flow ? (stall ? 2 : 1) : 0, table, w->cluster_slot.p, w->body_shared.p,
                              w->cluster_step ? w->cluster_slots : 0u); }
     if (flow) {

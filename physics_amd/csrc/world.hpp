@@ -207,9 +207,11 @@ struct phys_world {
     phys::DevBuf<uint32_t> scan_block_sums;
     phys::DevBuf<uint32_t> pairs;        // 2 * max_pairs
     // manifolds, geometry stage (storage order = emission order, arbitrary)
-    phys::DevBuf<uint32_t> man_a, man_b, man_count, man_color;
-    phys::DevBuf<float> man_normal;      // 3 per manifold
-    phys::DevBuf<float> man_points;      // 16 per manifold: 4 x (xyz, depth)
+    phys::DevBuf<uint32_t> man_a, man_b, man_color;  // SoA: what the colouring rounds and the row sort scan again and again
+    // geometry of a manifold as ONE 128-byte record = one cache line (32 floats: {a, b, count, -} {normal, -} 4 x {point,
+    // depth}, 32 bytes spare): k_rows_build reads it through the row permutation, and seven scattered 4-to-64-byte
+    // accesses per row had cost it 896 bytes of line fetches for 88 useful ones
+    phys::DevBuf<float> man_geo;
     phys::DevBuf<uint64_t> man_prio;
     // persistent colouring: two hash tables (this update's / the previous update's), key -> colour
     phys::DevBuf<uint64_t> ctab_keys[2];
@@ -242,6 +244,7 @@ struct phys_world {
     // cluster solver (cluster.hip): spatial clusters fixed at phys_set_bodies, rows sorted by (cluster, colour) per step
     uint32_t cluster_count = 0, cluster_slots = 0;  // 0 clusters: not available for this scene
     bool cluster_step = false;                      // this update's rows are in (cluster, colour) order
+    bool cluster_pair = false;                      // k_solve_cluster_pair (two lanes per row) instead of k_solve_cluster
     phys::DevBuf<uint32_t> cluster_slot;   // body -> cluster * slots + slot
     phys::DevBuf<uint32_t> cluster_body;   // cluster * slots + slot -> body (0xFFFFFFFF: empty)
     phys::DevBuf<uint32_t> body_shared;    // 2 per body: 64-bit mask of the colours in which ANOTHER cluster's row updates it

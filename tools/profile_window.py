@@ -34,7 +34,7 @@ def window_rows(rows, k, name_key, order_key):
 
 def find(base, sub, pattern):
     hits = glob.glob(os.path.join(base, sub, "**", pattern), recursive=True)
-    return hits[0] if hits else None
+    return max(hits, key=os.path.getmtime) if hits else None  # the newest pass (a directory may hold earlier ones)
 
 
 def main():
