@@ -81,14 +81,34 @@ PHYS_HD void tangent_basis(v3 n, v3* t1, v3* t2) {
     *t2 = v3_cross(n, t);
 }
 
+/* inverse inertia times a vector in the contact solver. A DIAGONAL tensor (the reference's only case: identity,
+ * rigid_body.rs:71) is applied as its three products; the six products with the zero off-diagonals that the general
+ * product adds could only change the sign of a zero result (for finite operands). The rule is per tensor, so the
+ * oracle and every solver kernel apply it alike, whatever else the world holds. */
+PHYS_HD int m33_is_diagonal(const m33* M) {
+    return M->m[1] == 0.0f && M->m[2] == 0.0f && M->m[3] == 0.0f && M->m[5] == 0.0f && M->m[6] == 0.0f && M->m[7] == 0.0f;
+}
+PHYS_HD v3 inertia_mul(const m33* I, v3 a) {
+    if (m33_is_diagonal(I)) return v3_make(I->m[0] * a.x, I->m[4] * a.y, I->m[8] * a.z);
+    return m33_mul_v3(I, a);
+}
+
 PHYS_HD float direction_mass(v3 dir, v3 rA, v3 rB, float invMA, const m33* IA, float invMB, const m33* IB, int has_b) {
     const v3 ra = v3_cross(rA, dir);
-    float k = invMA + v3_dot(m33_mul_v3(IA, ra), ra);
+    float k = invMA + v3_dot(inertia_mul(IA, ra), ra);
     if (has_b) {
         const v3 rb = v3_cross(rB, dir);
-        k = (k + invMB) + v3_dot(m33_mul_v3(IB, rb), rb);
+        k = (k + invMB) + v3_dot(inertia_mul(IB, rb), rb);
     }
     return k > 0.0f ? 1.0f / k : 0.0f;
+}
+
+/* velocity the normal row of a point asks for: push out beyond the slop, or let a speculative contact close its gap */
+PHYS_HD float contact_bias(float depth, const solve_params_t* sp) {
+    float bias = 0.0f;
+    if (depth > sp->slop) bias = det_minf((sp->baumgarte / sp->dt) * (depth - sp->slop), sp->max_bias);
+    else if (depth < 0.0f) bias = depth / sp->dt; /* speculative: may close the gap, not more */
+    return bias;
 }
 
 /* build the solver rows of one manifold. xB / invMB / IB are ignored when has_b == 0. */
@@ -106,11 +126,7 @@ PHYS_HD void solver_prep(const manifold_t* m, int has_b, v3 xA, v3 xB, float inv
             r->normal_mass = direction_mass(out->n, r->rA, r->rB, invMA, IA, invMB, IB, has_b);
             r->tangent_mass[0] = direction_mass(out->t1, r->rA, r->rB, invMA, IA, invMB, IB, has_b);
             r->tangent_mass[1] = direction_mass(out->t2, r->rA, r->rB, invMA, IA, invMB, IB, has_b);
-            const float depth = m->depth[k];
-            float bias = 0.0f;
-            if (depth > sp->slop) bias = det_minf((sp->baumgarte / sp->dt) * (depth - sp->slop), sp->max_bias);
-            else if (depth < 0.0f) bias = depth / sp->dt; /* speculative: may close the gap, not more */
-            r->bias = bias;
+            r->bias = contact_bias(m->depth[k], sp);
         } else {
             r->rA = v3_make(0.0f, 0.0f, 0.0f);
             r->rB = v3_make(0.0f, 0.0f, 0.0f);
@@ -134,10 +150,10 @@ typedef struct {
 PHYS_HD void jac_row_make(const solver_manifold_t* sm, int k, v3 dir, const m33* IA, const m33* IB, jac_row_t* j) {
     const v3 zero = v3_make(0.0f, 0.0f, 0.0f);
     j->aA = v3_cross(sm->row[k].rA, dir);
-    j->mA = m33_mul_v3(IA, j->aA);
+    j->mA = inertia_mul(IA, j->aA);
     if (sm->has_b) {
         j->aB = v3_cross(sm->row[k].rB, dir);
-        j->mB = m33_mul_v3(IB, j->aB);
+        j->mB = inertia_mul(IB, j->aB);
     } else {
         j->aB = zero; j->mB = zero;
     }
@@ -239,6 +255,79 @@ PHYS_HD void solve_manifold_lazy(solver_manifold_t* sm, float friction, float in
                 jac_row_t j;
                 jac_row_make(sm, k, t == 0 ? sm->t1 : (t == 1 ? sm->t2 : sm->n), IA, IB, &j);
                 solve_row_dir(sm, k, t, &j, lA[t], lB[t], friction, vA, wA, vB, wB);
+            }
+        }
+    }
+}
+
+/* ... or with NOTHING made beforehand but the bias: lever arms and Jacobians of a point are remade from the contact
+ * point, the two body positions and the mass properties whenever the point is solved, and so are the three row masses
+ * in a sweep with make_masses != 0 (the first one), which leaves them in gm->mass for the later sweeps. For a solver
+ * that streams its rows from memory once per iteration this is 28 bytes per point instead of 40 and no pass over the
+ * bodies to prepare them. The operations are those of solver_prep / direction_mass / jac_row_make on the same inputs,
+ * so the values are the same. */
+typedef struct {
+    v3 n, t1, t2;
+    int count;
+    int has_b;
+    v3 pt[4];      /* world-space contact points */
+    float bias[4]; /* contact_bias(depth) */
+    float pn[4], pt0[4], pt1[4]; /* accumulated impulses */
+    float mass[4][3];            /* row masses of t1, t2, n per point */
+} geo_manifold_t;
+
+PHYS_HD void solve_manifold_geo(geo_manifold_t* gm, int make_masses, float friction, v3 xA, float invMA, const m33* IA, v3 xB,
+                                float invMB, const m33* IB, v3* vA, v3* wA, v3* vB, v3* wB) {
+    const v3 zero = v3_make(0.0f, 0.0f, 0.0f);
+    const int has_b = gm->has_b;
+    v3 lA[3], lB[3];
+    PHYS_UNROLL
+    for (int d = 0; d < 3; ++d) {
+        const v3 dir = d == 0 ? gm->t1 : (d == 1 ? gm->t2 : gm->n);
+        lA[d] = v3_scale(dir, invMA);
+        lB[d] = has_b ? v3_scale(dir, invMB) : zero;
+    }
+    PHYS_UNROLL
+    for (int k = 0; k < 4; ++k) {
+        if (k < gm->count) {
+            const v3 rA = v3_sub(gm->pt[k], xA);                 /* solver_prep */
+            const v3 rB = has_b ? v3_sub(gm->pt[k], xB) : zero;
+            PHYS_UNROLL
+            for (int t = 0; t < 3; ++t) {
+                const v3 dir = t == 0 ? gm->t1 : (t == 1 ? gm->t2 : gm->n);
+                jac_row_t j;
+                j.aA = v3_cross(rA, dir);                        /* jac_row_make */
+                j.mA = inertia_mul(IA, j.aA);
+                if (has_b) {
+                    j.aB = v3_cross(rB, dir);
+                    j.mB = inertia_mul(IB, j.aB);
+                } else {
+                    j.aB = zero; j.mB = zero;
+                }
+                if (make_masses) {                               /* direction_mass: its ra, IA ra are aA, mA */
+                    float km = invMA + v3_dot(j.mA, j.aA);
+                    if (has_b) km = (km + invMB) + v3_dot(j.mB, j.aB);
+                    gm->mass[k][t] = km > 0.0f ? 1.0f / km : 0.0f;
+                }
+                const float mass = gm->mass[k][t];
+                const float vrel = row_velocity(dir, &j, has_b, *vA, *wA, *vB, *wB);
+                float lambda;
+                if (t < 2) {                                     /* solve_row_dir */
+                    float* acc = t == 0 ? &gm->pt0[k] : &gm->pt1[k];
+                    lambda = -mass * vrel;
+                    const float maxf = friction * gm->pn[k];
+                    const float old = *acc;
+                    const float np = det_maxf(-maxf, det_minf(old + lambda, maxf));
+                    lambda = np - old;
+                    *acc = np;
+                } else {
+                    lambda = mass * (gm->bias[k] - vrel);
+                    const float old = gm->pn[k];
+                    const float np = det_maxf(old + lambda, 0.0f);
+                    lambda = np - old;
+                    gm->pn[k] = np;
+                }
+                row_apply(lambda, lA[t], lB[t], &j, has_b, vA, wA, vB, wB);
             }
         }
     }

@@ -336,8 +336,8 @@ void oracle_det_atan2(const float* y, const float* x, uint64_t n, float* out) {
     for (uint64_t k = 0; k < n; ++k) out[k] = det_atan2f(y[k], x[k]);
 }
 
-// contact_solve.h has two drivers of the row arithmetic (Jacobians made beforehand / on the way); the HIP kernels
-// use both. Runs `iters` sweeps of each on one manifold described by flat arrays; returns the number of output
+// contact_solve.h has three drivers of the row arithmetic (Jacobians made beforehand / on the way / everything
+// remade from the contact geometry); the HIP kernels use all of them. Runs `iters` sweeps of each on one manifold described by flat arrays; returns the number of output
 // floats whose BITS differ (must be 0). in: normal 3, count, has_b, 4 x (rA 3, rB 3, depth) = 28 floats + invMA,
 // invMB, IA 9, IB 9, vA 3, wA 3, vB 3, wB 3, friction; see tests/test_collide_kat.py.
 int32_t oracle_solve_drivers_mismatch(const float* in, int32_t count, int32_t has_b, int32_t iters) {
@@ -345,7 +345,7 @@ int32_t oracle_solve_drivers_mismatch(const float* in, int32_t count, int32_t ha
     g.normal = v3_make(in[0], in[1], in[2]);
     g.count = count;
     const float* p = in + 3;
-    v3 xA = v3_make(0.0f, 0.0f, 0.0f), xB = v3_make(p[28], p[29], p[30]);
+    v3 xA = v3_make(0.25f * p[29], -0.5f * p[30], 0.125f * p[28]), xB = v3_make(p[28], p[29], p[30]);
     for (int k = 0; k < 4; ++k) { g.pt[k] = v3_make(p[7 * k], p[7 * k + 1], p[7 * k + 2]); g.depth[k] = p[7 * k + 6]; }
     const float invMA = p[31], invMB = p[32];
     m33 IA, IB;
@@ -356,19 +356,33 @@ int32_t oracle_solve_drivers_mismatch(const float* in, int32_t count, int32_t ha
     solver_manifold_t a, b;
     solver_prep(&g, has_b, xA, xB, invMA, &IA, invMB, &IB, &sp, &a);
     b = a;
-    v3 va[4], vb[4];
-    for (int k = 0; k < 4; ++k) va[k] = vb[k] = v3_make(p[51 + 3 * k], p[52 + 3 * k], p[53 + 3 * k]);
+    geo_manifold_t c;
+    c.n = a.n; c.t1 = a.t1; c.t2 = a.t2; c.count = count; c.has_b = has_b;
+    for (int k = 0; k < 4; ++k) {
+        c.pt[k] = g.pt[k];
+        c.bias[k] = contact_bias(g.depth[k], &sp);
+        c.pn[k] = 0.0f; c.pt0[k] = 0.0f; c.pt1[k] = 0.0f;
+    }
+    v3 va[4], vb[4], vc[4];
+    for (int k = 0; k < 4; ++k) va[k] = vb[k] = vc[k] = v3_make(p[51 + 3 * k], p[52 + 3 * k], p[53 + 3 * k]);
     solver_jac_t J;
     solver_jacobians(&a, invMA, &IA, invMB, &IB, &J);
     for (int it = 0; it < iters; ++it) {
         solve_manifold(&a, &J, friction, &va[0], &va[1], &va[2], &va[3]);
         solve_manifold_lazy(&b, friction, invMA, &IA, invMB, &IB, &vb[0], &vb[1], &vb[2], &vb[3]);
+        solve_manifold_geo(&c, it == 0, friction, xA, invMA, &IA, xB, invMB, &IB, &vc[0], &vc[1], &vc[2], &vc[3]);
     }
     int32_t bad = 0;
     for (int k = 0; k < 4; ++k) bad += std::memcmp(&va[k], &vb[k], sizeof(v3)) != 0;
+    for (int k = 0; k < 4; ++k) bad += std::memcmp(&va[k], &vc[k], sizeof(v3)) != 0;
     for (int k = 0; k < 4; ++k) {
         bad += std::memcmp(&a.row[k].pn, &b.row[k].pn, 4) != 0;
         bad += std::memcmp(a.row[k].pt, b.row[k].pt, 8) != 0;
+        if (k < count) {
+            bad += std::memcmp(&a.row[k].pn, &c.pn[k], 4) != 0;
+            bad += std::memcmp(&a.row[k].pt[0], &c.pt0[k], 4) != 0;
+            bad += std::memcmp(&a.row[k].pt[1], &c.pt1[k], 4) != 0;
+        }
     }
     return bad;
 }

@@ -32,7 +32,8 @@ namespace phys {
 // occupancy asked for: three workgroups per CU (3 waves per SIMD, <= 168 VGPRs; at 128 the kernel spills 2) with diagonal
 // tensors, two otherwise. Measured on C5, same bits: 1 per CU 3.48 ms, 2 per CU 2.70, 3 per CU 2.20
 constexpr int kClusterPerCuDiag = 3, kClusterPerCuFull = 2;
-constexpr int kClusterPairPerCuDecl = 4;  // == kClusterPairPerCu of k_solve_cluster_pair below
+constexpr size_t kClusterLdsPerCu = 160 * 1024;
+size_t cluster_lds_bytes(uint32_t slots);
 
 // per-row side info packed into row_n.w (as bits): slot (16) | mode (2) per side
 //   mode 0: own cluster, never shared -> LDS only          1: own cluster, shared -> LDS while its tag is current, else granule
@@ -60,16 +61,20 @@ int32_t cluster_assign(phys_world* w, const float* pos /* host, 3 * n_owned */) 
     // solve); an eighth of the chip to spare: EVERY workgroup must be resident (the kernel's occupancy bound admits
     // kClusterPerCu* of them per CU; a workgroup that found no room would be waited for until the time-out)
     static const char* per_cu_env = getenv("PHYS_DEBUG_CLUSTERS_PER_CU");
-    // two lanes per row (k_solve_cluster_pair, four workgroups per CU) with diagonal tensors; PHYS_DEBUG_CLUSTER_KERNEL=lane
-    // keeps the one-lane kernel (A/B measurements; same bits)
-    static const char* kernel_env = getenv("PHYS_DEBUG_CLUSTER_KERNEL");
-    w->cluster_pair = w->all_diag_inertia && !(kernel_env && kernel_env[0] == 'l');
-    const int per_cu_max = w->cluster_pair ? kClusterPairPerCuDecl : (w->all_diag_inertia ? kClusterPerCuDiag : kClusterPerCuFull);
-    const int per_cu = per_cu_env ? std::min(per_cu_max, std::max(1, atoi(per_cu_env))) : per_cu_max;
-    const uint32_t max_clusters = (uint32_t)std::max(8, per_cu * (cus - cus / 8));
-    uint32_t slots = (uint32_t)((n + max_clusters - 1) / max_clusters);
-    slots = (slots + 63u) / 64u * 64u;
-    if (slots > kClusterMaxSlots) return PHYS_OK;  // velocities would not fit the CU's LDS: per-colour launches
+    const int per_cu_max = w->all_diag_inertia ? kClusterPerCuDiag : kClusterPerCuFull;
+    int per_cu = per_cu_env ? std::min(per_cu_max, std::max(1, atoi(per_cu_env))) : per_cu_max;
+    static const int spare_div = getenv("PHYS_DEBUG_CLUSTER_SPARE") ? atoi(getenv("PHYS_DEBUG_CLUSTER_SPARE")) : 8;
+    uint32_t slots = 0;
+    // ... and the LDS of a CU must hold all of its workgroups' bodies (64 B per slot + the segment table, in 1 KiB
+    // allocation units), or the grid would not be resident: fewer, larger clusters per CU until it does
+    for (;; --per_cu) {
+        const uint32_t max_clusters = (uint32_t)std::max(8, per_cu * (cus - (spare_div ? cus / spare_div : 0)));
+        slots = (uint32_t)((n + max_clusters - 1) / max_clusters);
+        slots = (slots + 63u) / 64u * 64u;
+        const size_t per_wg = (cluster_lds_bytes(slots) + 1023) / 1024 * 1024;
+        if (per_wg * (size_t)per_cu <= kClusterLdsPerCu && slots <= kClusterMaxSlots) break;
+        if (per_cu == 1) return PHYS_OK;  // the bodies would not fit the CU's LDS: per-colour launches
+    }
     const uint32_t clusters = (uint32_t)((n + slots - 1) / slots);
     // isotropic Morton key over the bounding box of the owned bodies (ghost slots: behind everybody)
     float lo[3] = {3e38f, 3e38f, 3e38f}, hi[3] = {-3e38f, -3e38f, -3e38f};
@@ -165,7 +170,10 @@ void launch_cluster_sort(phys_world* w, unsigned blocks) {
 // ---- the solver ----------------------------------------------------------------------------------------------
 typedef uint32_t u32x4c __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ u32x4c ld_gran(__amdgpu_buffer_rsrc_t r, uint32_t byte_off) {
-    return __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, (int)0x80000010);  // sc1, volatile
+    // agent scope (sc1): the other XCDs' write-through stores are seen, this XCD's L2 is not trusted. (The volatile
+    // form adds sc0 = system scope.) The compiler barrier makes every poll a new load.
+    asm volatile("" ::: "memory");
+    return __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, (int)0x10);
 }
 __device__ __forceinline__ void st_gran(__amdgpu_buffer_rsrc_t r, uint32_t byte_off, v3 v, uint32_t tag) {
     u32x4c g;
@@ -173,75 +181,120 @@ __device__ __forceinline__ void st_gran(__amdgpu_buffer_rsrc_t r, uint32_t byte_
     __builtin_amdgcn_raw_buffer_store_b128(g, r, byte_off, 0, 16);  // sc1: write-through
 }
 
-struct ClusterRowArrays { uint4* hdr; float4* n; float4* pt; float4* tb; float4* acc; uint64_t cap; };
+// Rows of a cluster step are COMPACT (k_rows_build writes them so when cluster_slots != 0): what the solver streams
+// per iteration is 9 planes of 16 bytes instead of 16 -
+//     plane 0      hdr {body a, body b, point count, tickets}
+//     plane 1      n   {normal, per-side slot | publish | mode}
+//     planes 2-5   geo {contact point k (world), bias k}
+//     planes 6-8   acc the 12 accumulated impulses {pn, pt0, pt1} x 4, packed
+//     planes 9-11  the 12 row masses {t1, t2, n} x 4, packed: written by the solver itself in iteration 0, read after
+//     planes 12-13 rows whose body B belongs to ANOTHER cluster: {position of B, 1/m} {inverse inertia diagonal of B}
+//                  (what never changes during a solve; gathering it by body id after the row has arrived was a second
+//                  dependent round trip to memory in the chain of every colour step: 2.08 -> ~1.2 ms on C5)
+// and everything else solver_prep would have stored (the lever arms) is remade from the contact point and the two body
+// POSITIONS, which live in LDS beside the velocities (solve_manifold_geo: same operations, same bits;
+// tests/test_collide_kat.py holds the three drivers against each other). So k_rows_build reads nothing of the bodies
+// on a cluster step, and a 4-point row is 240 bytes per iteration instead of 320.
+struct ClusterRowArrays { float4* all; uint64_t cap; };
+constexpr int kClusterPlaneHdr = 0, kClusterPlaneN = 1, kClusterPlaneGeo = 2, kClusterPlaneAcc = 6, kClusterPlaneMass = 9, kClusterPlaneForeign = 12;
+constexpr uint32_t kClusterSlotBytes = 64;  // LDS per body slot: {v, tag} {w, 1/m} {x, -} {inverse inertia diagonal, -}
+size_t cluster_lds_bytes(uint32_t slots) { return (size_t)slots * kClusterSlotBytes + (PHYS_MAX_COLORS + 1) * 4 + 12; }
 
-constexpr int kClusterThreads = 256;  // two workgroups (clusters) per CU: one streams rows while the other computes
+constexpr int kClusterThreads = 256;
 template <bool DIAG>
 __global__ __launch_bounds__(kClusterThreads, DIAG ? kClusterPerCuDiag : kClusterPerCuFull) void k_solve_cluster(StepCounters* ctr, uint32_t iterations, uint32_t epoch,
                                                                   ClusterRowArrays rows, float friction,
                                                                   const float* __restrict__ inv_inertia, uint32_t inertia_stride,
-                                                                  float* vel, float* flow_vel, uint32_t n_bodies,
+                                                                  float* vel, const float* __restrict__ pos, float* flow_vel, uint32_t n_bodies,
                                                                   const uint32_t* __restrict__ cluster_body,
                                                                   const uint32_t* __restrict__ body_shared,
                                                                   const uint32_t* __restrict__ seg_start, uint32_t slots,
                                                                   long long timeout_ticks, uint32_t ablate) {
-    extern __shared__ __attribute__((aligned(16))) float4 s_lds[];  // [2 * slots]: {v, tag} {w, 1/m};  then the segment table
-    float4* s_vel = s_lds;
-    uint32_t* s_seg = reinterpret_cast<uint32_t*>(s_lds + 2 * (size_t)slots);  // PHYS_MAX_COLORS + 1 row offsets
+    extern __shared__ __attribute__((aligned(16))) float4 s_lds[];  // [4 * slots]: {v, tag} {w, 1/m} {x} {I^-1 diag};  then the segment table
+    float4* s_body = s_lds;
+    uint32_t* s_seg = reinterpret_cast<uint32_t*>(s_lds + 4 * (size_t)slots);  // PHYS_MAX_COLORS + 1 row offsets
     if (ctr->overflow) return;
     const uint32_t cluster = blockIdx.x;
     const uint32_t n_colors = ctr->n_colors;
     const uint32_t etag = epoch << 16;
-    const uint32_t cap = (uint32_t)rows.cap;
+    const size_t cap = (size_t)rows.cap;
     const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(flow_vel, 0, n_bodies * 32u, 0x00020000);
     // own bodies into LDS; tag "no update applied yet"
     for (uint32_t sl = threadIdx.x; sl < slots; sl += kClusterThreads) {
         const uint32_t body = cluster_body[(size_t)cluster * slots + sl];
-        float4 a = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(etag)), b = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        float4 a = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(etag)), b = make_float4(0.0f, 0.0f, 0.0f, 0.0f), c = b, e = b;
         if (body != 0xFFFFFFFFu) {
             const float4 v0 = reinterpret_cast<const float4*>(vel)[2 * (size_t)body];
             const float4 v1 = reinterpret_cast<const float4*>(vel)[2 * (size_t)body + 1];
+            const v3 x = ld3(pos, body);
             a = make_float4(v0.x, v0.y, v0.z, __uint_as_float(etag));
             b = make_float4(v1.x, v1.y, v1.z, v0.w);
+            c = make_float4(x.x, x.y, x.z, 0.0f);
+            if (DIAG) e = reinterpret_cast<const float4*>(inv_inertia)[body * inertia_stride];
         }
-        s_vel[2 * sl] = a;
-        s_vel[2 * sl + 1] = b;
+        s_body[4 * sl] = a;
+        s_body[4 * sl + 1] = b;
+        s_body[4 * sl + 2] = c;
+        s_body[4 * sl + 3] = e;
     }
     if (threadIdx.x <= (uint32_t)PHYS_MAX_COLORS) s_seg[threadIdx.x] = seg_start[(size_t)cluster * PHYS_MAX_COLORS + threadIdx.x];
     __syncthreads();
     const long long t_start = wall_clock64();
     bool dead = false;
-    // (Measured and dropped: a second register set prefetching the lane's row of the next colour step - 252 VGPRs, the
-    // compiler's waits drained it with the current row: 2.72 vs 2.52 ms on C5; touching the next rows into the L2: 3.18.
-    // What overlaps memory with arithmetic here is a SECOND workgroup on the same CU - two clusters per CU.)
-    struct RowRaw { uint4 h; float4 nn, t01, t23, p0[4], p1[4], ac[4]; };
-    auto fetch = [&](uint32_t d, bool with_acc, RowRaw& r) {
+    // (Measured and dropped, all bit-identical: touching the next rows into the L2, 3.18 vs 2.52 ms on C5; two lanes per
+    // row, the halves of the relative velocity exchanged by DPP, four workgroups per CU: 2.99 vs 2.20 - 1.5x the load
+    // instructions and the scalar part of every row done twice; rotating the wave a colour segment starts on: no change.)
+    //
+    // ROWS ARE FETCHED ONE OR TWO COLOUR STEPS AHEAD. A colour step of a cluster has fewer rows than the workgroup has
+    // lanes (C5: ~130 of 256), and what a step costs is a chain - row fetch (2-3 us from HBM), LDS, ~1500 dependent
+    // instructions, publish, barrier - that the few workgroups of a CU cannot hide from each other (ablation at three per
+    // CU: 5.0 us of the 7.6 us per step remain with neither arithmetic nor granules). So the rows of the cluster, which are
+    // contiguous and in colour order, are dealt to the lanes round robin: lane l solves rows base + l, base + l + 256, ... of
+    // every iteration, and asks for its next row the moment it has finished one - one or two steps before that row's colour
+    // comes up. The row waits in the registers it would occupy anyway. The barrier between steps is a bare s_barrier behind
+    // an LDS wait (inline asm): __syncthreads() would make every wave wait for the loads it has just issued. Only LDS
+    // traffic has to be ordered by it; the planes a lane reads back (impulses, masses) it wrote itself.
+    const uint32_t steps = iterations * n_colors;
+    const uint32_t row_base = s_seg[0], row_end = s_seg[n_colors];
+    uint32_t d = row_base + threadIdx.x;  // this lane's next row ...
+    uint32_t lit = 0;                     // ... and the iteration it belongs to
+    bool have = d < row_end && iterations != 0u;
+    float4 hraw, nn, geo[4], acc[3], mas[3], fb, fi;
+    auto fetch = [&]() {
         // every plane at once, whatever the point count turns out to be (planes beyond it hold stale, readable data that
         // is ignored): ONE round trip to memory
-        r.h = rows.hdr[d];
-        r.nn = rows.n[d];
-        r.t01 = rows.tb[d];
-        r.t23 = rows.tb[cap + d];
+        const float4* row = rows.all + d;
+        hraw = row[kClusterPlaneHdr * cap];
+        nn = row[kClusterPlaneN * cap];
+        fb = row[kClusterPlaneForeign * cap];  // stale (and ignored) unless body B is another cluster's
+        if (DIAG) fi = row[(kClusterPlaneForeign + 1) * cap];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            r.p0[k] = rows.pt[(size_t)(2 * k) * cap + d];
-            r.p1[k] = rows.pt[(size_t)(2 * k + 1) * cap + d];
-            r.ac[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            if (with_acc) r.ac[k] = rows.acc[(size_t)k * cap + d];  // written by this very lane one iteration ago
+        for (int k = 0; k < 4; ++k) geo[k] = row[(kClusterPlaneGeo + k) * cap];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            acc[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            mas[k] = acc[k];
+            if (lit != 0u) {  // written by this very lane: the impulses one iteration ago, the masses in iteration 0
+                acc[k] = row[(kClusterPlaneAcc + k) * cap];
+                mas[k] = row[(kClusterPlaneMass + k) * cap];
+            }
         }
     };
-    const uint32_t steps = iterations * n_colors;
+    hraw = make_float4(0.0f, 0.0f, 0.0f, 0.0f); nn = hraw; fb = hraw; fi = hraw;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) geo[k] = hraw;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { acc[k] = hraw; mas[k] = hraw; }
+    if (have) fetch();
     uint32_t it = 0, col = 0;
     for (uint32_t step = 0; step < steps; ++step) {
         const bool last_it = it + 1 == iterations;
         {
-            const uint32_t seg_lo = s_seg[col], seg_hi = s_seg[col + 1];
-            for (uint32_t d = seg_lo + threadIdx.x; d < seg_hi; d += kClusterThreads) {
-                RowRaw r;
-                fetch(d, it != 0u, r);
-                const uint4 h = r.h;
-                const float4 nn = r.nn;
-                const float4 t01 = r.t01, t23r = r.t23;
+            const uint32_t seg_hi = s_seg[col + 1];
+            // the lane's row is never of an earlier colour of this iteration (it would have been solved then)
+            while (have && lit == it && d < seg_hi) {
+                const uint32_t d_row = d;
+                const uint4 h = make_uint4(__float_as_uint(hraw.x), __float_as_uint(hraw.y), __float_as_uint(hraw.z), __float_as_uint(hraw.w));
                 const uint32_t info = __float_as_uint(nn.w);
                 // slot (13 bits) | publish (1) | mode (2) per side. publish: the NEXT update of this (shared, own) body is
                 // made by another workgroup, so this update must reach the granules; otherwise it stays in LDS
@@ -249,54 +302,61 @@ __global__ __launch_bounds__(kClusterThreads, DIAG ? kClusterPerCuDiag : kCluste
                 const uint32_t slotA = info & 0x1FFFu, slotB = (info >> 16) & 0x1FFFu;
                 const bool pubA = (info >> 13) & 1u, pubB = (info >> 29) & 1u;
                 if (ablate & 8u) { modeA = 0u; if (modeB == 1u) modeB = 0u; }  // PHYS_DEBUG_ABLATE (timing only, wrong results)
-                solver_manifold_t sm;
-                sm.count = (int)h.z;
-                sm.has_b = h.y != PHYS_GROUND_ID;
-                sm.n = v3_make(nn.x, nn.y, nn.z);
-                tangent_basis(sm.n, &sm.t1, &sm.t2);
-                float4 t23 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                if (sm.count > 2) t23 = t23r;
+                geo_manifold_t gm;
+                gm.count = (int)h.z;
+                gm.has_b = h.y != PHYS_GROUND_ID;
+                gm.n = v3_make(nn.x, nn.y, nn.z);
+                tangent_basis(gm.n, &gm.t1, &gm.t2);
+                {
+                    const float flat[12] = {acc[0].x, acc[0].y, acc[0].z, acc[0].w, acc[1].x, acc[1].y, acc[1].z, acc[1].w,
+                                            acc[2].x, acc[2].y, acc[2].z, acc[2].w};
+                    const float flam[12] = {mas[0].x, mas[0].y, mas[0].z, mas[0].w, mas[1].x, mas[1].y, mas[1].z, mas[1].w,
+                                            mas[2].x, mas[2].y, mas[2].z, mas[2].w};
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    contact_row_t& c = sm.row[k];
-                    c.rA = v3_make(0.0f, 0.0f, 0.0f); c.rB = v3_make(0.0f, 0.0f, 0.0f);
-                    c.normal_mass = 0.0f; c.tangent_mass[0] = 0.0f; c.tangent_mass[1] = 0.0f; c.bias = 0.0f;
-                    c.pn = 0.0f; c.pt[0] = 0.0f; c.pt[1] = 0.0f;
-                    if (k < sm.count) {
-                        c.rA = v3_make(r.p0[k].x, r.p0[k].y, r.p0[k].z); c.normal_mass = r.p0[k].w;
-                        c.rB = v3_make(r.p1[k].x, r.p1[k].y, r.p1[k].z); c.tangent_mass[0] = r.p1[k].w;
-                        const float4 t = k < 2 ? t01 : t23;
-                        c.tangent_mass[1] = (k & 1) ? t.z : t.x;
-                        c.bias = (k & 1) ? t.w : t.y;
-                        if (it != 0) { c.pn = r.ac[k].x; c.pt[0] = r.ac[k].y; c.pt[1] = r.ac[k].z; }
+                    for (int k = 0; k < 4; ++k) {
+                        gm.pt[k] = v3_make(geo[k].x, geo[k].y, geo[k].z);
+                        gm.bias[k] = geo[k].w;
+                        gm.pn[k] = flat[3 * k]; gm.pt0[k] = flat[3 * k + 1]; gm.pt1[k] = flat[3 * k + 2];
+                        gm.mass[k][0] = flam[3 * k]; gm.mass[k][1] = flam[3 * k + 1]; gm.mass[k][2] = flam[3 * k + 2];
                     }
                 }
                 const uint32_t rankA = h.w & 0xFFu, degA = (h.w >> 8) & 0xFFu, rankB = (h.w >> 16) & 0xFFu, degB = h.w >> 24;
                 const uint32_t tA = it * degA + rankA, tB = it * degB + rankB;
                 const bool finalA = last_it && rankA + 1 == degA, finalB = last_it && rankB + 1 == degB;
                 // ---- the two bodies
-                v3 vA, wA, vB = v3_make(0.0f, 0.0f, 0.0f), wB = vB;
-                float ima, imb = 0.0f, massA = 0.0f, massB = 0.0f;
+                v3 vA, wA, xA, vB = v3_make(0.0f, 0.0f, 0.0f), wB = vB, xB = vB;
+                float ima, imb = 0.0f;
                 bool needA = false, needB = false;
+                m33 IA, IB;
+#pragma unroll
+                for (int k = 0; k < 9; ++k) { IA.m[k] = 0.0f; IB.m[k] = 0.0f; }
                 {
-                    const float4 la = s_vel[2 * slotA], lb = s_vel[2 * slotA + 1];  // A is always of this cluster
+                    const float4* sa = s_body + 4 * slotA;  // A is always of this cluster
+                    const float4 la = sa[0], lb = sa[1], lc = sa[2];
                     vA = v3_make(la.x, la.y, la.z); wA = v3_make(lb.x, lb.y, lb.z); ima = lb.w;
-                    if (modeA == 1u) {
-                        needA = __float_as_uint(la.w) != (etag | tA);  // a remote row made the update before this one
-                        if (finalA) massA = vel[8 * (size_t)h.x + 7];
-                    }
+                    xA = v3_make(lc.x, lc.y, lc.z);
+                    if (DIAG) { const float4 li = sa[3]; IA.m[0] = li.x; IA.m[4] = li.y; IA.m[8] = li.z; }
+                    if (modeA == 1u) needA = __float_as_uint(la.w) != (etag | tA);  // a remote row made the update before this one
                 }
                 if (modeB == 0u || modeB == 1u) {
-                    const float4 la = s_vel[2 * slotB], lb = s_vel[2 * slotB + 1];
+                    const float4* sb = s_body + 4 * slotB;
+                    const float4 la = sb[0], lb = sb[1], lc = sb[2];
                     vB = v3_make(la.x, la.y, la.z); wB = v3_make(lb.x, lb.y, lb.z); imb = lb.w;
-                    if (modeB == 1u) {
-                        needB = __float_as_uint(la.w) != (etag | tB);
-                        if (finalB) massB = vel[8 * (size_t)h.y + 7];
-                    }
+                    xB = v3_make(lc.x, lc.y, lc.z);
+                    if (DIAG) { const float4 li = sb[3]; IB.m[0] = li.x; IB.m[4] = li.y; IB.m[8] = li.z; }
+                    if (modeB == 1u) needB = __float_as_uint(la.w) != (etag | tB);
                 } else if (modeB == 2u) {
-                    const BodyVel B0 = ld_vel(vel, h.y);  // the state itself for ticket 0, the masses always
-                    vB = B0.v; wB = B0.w; imb = B0.inv_mass; massB = B0.mass;
+                    xB = v3_make(fb.x, fb.y, fb.z); imb = fb.w;  // came with the row
+                    if (DIAG) { IB.m[0] = fi.x; IB.m[4] = fi.y; IB.m[8] = fi.z; }
+                    if (tB == 0u) {  // first update of that body in this solve (iteration 0 only): its state is still in `vel`
+                        const BodyVel B0 = ld_vel(vel, h.y);
+                        vB = B0.v; wB = B0.w;
+                    }
                     needB = tB != 0u && !(ablate & 8u);
+                }
+                if (!DIAG) {  // full tensors: gathered by body id (the rare path keeps its second round trip)
+                    IA = ld_inertia_c<false>(inv_inertia, h.x * inertia_stride);
+                    if (gm.has_b) IB = ld_inertia_c<false>(inv_inertia, h.y * inertia_stride);
                 }
                 uint32_t sweeps = 0;
                 while (needA || needB) {
@@ -326,36 +386,42 @@ __global__ __launch_bounds__(kClusterThreads, DIAG ? kClusterPerCuDiag : kCluste
                     }
                 }
                 if (!dead) {
-                    const m33 IA = ld_inertia_c<DIAG>(inv_inertia, h.x * inertia_stride);
-                    m33 IB;
-#pragma unroll
-                    for (int k = 0; k < 9; ++k) IB.m[k] = 0.0f;
-                    if (sm.has_b) IB = ld_inertia_c<DIAG>(inv_inertia, h.y * inertia_stride);
-                    if (!(ablate & 2u)) solve_manifold_lazy(&sm, friction, ima, &IA, imb, &IB, &vA, &wA, &vB, &wB);
+                    if (!(ablate & 2u)) solve_manifold_geo(&gm, it == 0u || (ablate & 32u), friction, xA, ima, &IA, xB, imb, &IB, &vA, &wA, &vB, &wB);
                     // ---- write back
-                    s_vel[2 * slotA] = make_float4(vA.x, vA.y, vA.z, __uint_as_float(etag | (tA + 1u)));
-                    s_vel[2 * slotA + 1] = make_float4(wA.x, wA.y, wA.z, ima);
+                    s_body[4 * slotA] = make_float4(vA.x, vA.y, vA.z, __uint_as_float(etag | (tA + 1u)));
+                    s_body[4 * slotA + 1] = make_float4(wA.x, wA.y, wA.z, ima);
                     if (modeA == 1u) {
-                        if (finalA) { BodyVel o; o.v = vA; o.inv_mass = ima; o.w = wA; o.mass = massA; st_vel(vel, h.x, o); }
+                        if (finalA) { st3(vel + 8 * (size_t)h.x, 0, vA); st3(vel + 8 * (size_t)h.x + 4, 0, wA); }  // the masses stay where they are
                         else if (pubA) { st_gran(rv, h.x * 32u, vA, etag | (tA + 1u)); st_gran(rv, h.x * 32u + 16u, wA, etag | (tA + 1u)); }
                     }
                     if (modeB == 0u || modeB == 1u) {
-                        s_vel[2 * slotB] = make_float4(vB.x, vB.y, vB.z, __uint_as_float(etag | (tB + 1u)));
-                        s_vel[2 * slotB + 1] = make_float4(wB.x, wB.y, wB.z, imb);
+                        s_body[4 * slotB] = make_float4(vB.x, vB.y, vB.z, __uint_as_float(etag | (tB + 1u)));
+                        s_body[4 * slotB + 1] = make_float4(wB.x, wB.y, wB.z, imb);
                     }
                     if (modeB == 1u || modeB == 2u) {
-                        if (finalB) { BodyVel o; o.v = vB; o.inv_mass = imb; o.w = wB; o.mass = massB; st_vel(vel, h.y, o); }
+                        if (finalB) { st3(vel + 8 * (size_t)h.y, 0, vB); st3(vel + 8 * (size_t)h.y + 4, 0, wB); }
                         else if (modeB == 2u || pubB) { st_gran(rv, h.y * 32u, vB, etag | (tB + 1u)); st_gran(rv, h.y * 32u + 16u, wB, etag | (tB + 1u)); }
                     }
-                    if (!last_it) {
-#pragma unroll
-                        for (int k = 0; k < 4; ++k)
-                            if (k < sm.count)
-                                rows.acc[(size_t)k * cap + d] = make_float4(sm.row[k].pn, sm.row[k].pt[0], sm.row[k].pt[1], 0.0f);
+                    if (!last_it) {  // impulses of points beyond the count are whatever came in: never used
+                        float4* out = rows.all + d_row;
+                        out[(kClusterPlaneAcc + 0) * cap] = make_float4(gm.pn[0], gm.pt0[0], gm.pt1[0], gm.pn[1]);
+                        if (gm.count > 1) out[(kClusterPlaneAcc + 1) * cap] = make_float4(gm.pt0[1], gm.pt1[1], gm.pn[2], gm.pt0[2]);
+                        if (gm.count > 2) out[(kClusterPlaneAcc + 2) * cap] = make_float4(gm.pt1[2], gm.pn[3], gm.pt0[3], gm.pt1[3]);
+                        if (it == 0u) {
+                            out[(kClusterPlaneMass + 0) * cap] = make_float4(gm.mass[0][0], gm.mass[0][1], gm.mass[0][2], gm.mass[1][0]);
+                            if (gm.count > 1) out[(kClusterPlaneMass + 1) * cap] = make_float4(gm.mass[1][1], gm.mass[1][2], gm.mass[2][0], gm.mass[2][1]);
+                            if (gm.count > 2) out[(kClusterPlaneMass + 2) * cap] = make_float4(gm.mass[2][2], gm.mass[3][0], gm.mass[3][1], gm.mass[3][2]);
+                        }
                     }
                 }
+                // the lane's next row: 256 further on, or its first one again in the next iteration
+                d += kClusterThreads;
+                if (d >= row_end) { d = row_base + threadIdx.x; ++lit; }
+                have = lit < iterations && !dead;
+                if (have) fetch();
             }
-            __syncthreads();  // LDS velocities of this colour are in place before the next colour reads them
+            // LDS velocities of this colour are in place before the next colour reads them (see above: not __syncthreads)
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         }
         if (++col == n_colors) { col = 0u; ++it; }
     }
@@ -364,232 +430,18 @@ __global__ __launch_bounds__(kClusterThreads, DIAG ? kClusterPerCuDiag : kCluste
     for (uint32_t sl = threadIdx.x; sl < slots; sl += kClusterThreads) {
         const uint32_t body = cluster_body[(size_t)cluster * slots + sl];
         if (body == 0xFFFFFFFFu || (body_shared[2 * (size_t)body] | body_shared[2 * (size_t)body + 1])) continue;
-        const float4 a = s_vel[2 * sl], b = s_vel[2 * sl + 1];
-        float4* out = reinterpret_cast<float4*>(vel) + 2 * (size_t)body;
-        const float mass = out[1].w;
-        out[0] = make_float4(a.x, a.y, a.z, b.w);
-        out[1] = make_float4(b.x, b.y, b.z, mass);
+        const float4 a = s_body[4 * sl], b = s_body[4 * sl + 1];
+        st3(vel + 8 * (size_t)body, 0, v3_make(a.x, a.y, a.z));
+        st3(vel + 8 * (size_t)body + 4, 0, v3_make(b.x, b.y, b.z));
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------
-// The same solver with TWO LANES PER ROW: the even lane of a pair owns body A, the odd lane body B. At three
-// workgroups per CU the one-lane kernel is bound by the latency of a colour step - row fetch, then 12 sequential rows
-// of ~100 instructions each on lanes of which only half hold a row (C5: ~130 rows per step for 256 lanes). Here a
-// lane fetches its own side's planes, makes its own Jacobian column (r x dir, I^-1 (r x dir)) and its own half of the
-// relative velocity (dir.v + a.w); the halves meet through one DPP exchange inside the pair and are combined in the
-// order of the spec, ub - ua; both lanes then make the same scalar update and apply it to their own body. Half the
-// chain per lane, every lane busy, ~100 VGPRs (four workgroups per CU). Same arithmetic, same bits.
-constexpr int kPairXor1 = 0xB1;  // quad_perm [1, 0, 3, 2]
-__device__ __forceinline__ float pair_swap(float v) {
-    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), kPairXor1, 0xF, 0xF, true));
-}
-__device__ __forceinline__ uint32_t pair_swap_u(uint32_t v) {
-    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, kPairXor1, 0xF, 0xF, true);
-}
-
-constexpr int kClusterPairPerCu = kClusterPairPerCuDecl;
-template <bool DIAG>
-__global__ __launch_bounds__(kClusterThreads, kClusterPairPerCu) void k_solve_cluster_pair(
-    StepCounters* ctr, uint32_t iterations, uint32_t epoch, ClusterRowArrays rows, float friction,
-    const float* __restrict__ inv_inertia, uint32_t inertia_stride, float* vel, float* flow_vel, uint32_t n_bodies,
-    const uint32_t* __restrict__ cluster_body, const uint32_t* __restrict__ body_shared, const uint32_t* __restrict__ seg_start,
-    uint32_t slots, long long timeout_ticks) {
-    extern __shared__ __attribute__((aligned(16))) float4 s_lds2[];
-    float4* s_vel = s_lds2;
-    uint32_t* s_seg = reinterpret_cast<uint32_t*>(s_lds2 + 2 * (size_t)slots);
-    if (ctr->overflow) return;
-    const uint32_t cluster = blockIdx.x;
-    const uint32_t n_colors = ctr->n_colors;
-    const uint32_t etag = epoch << 16;
-    const uint32_t cap = (uint32_t)rows.cap;
-    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(flow_vel, 0, n_bodies * 32u, 0x00020000);
-    for (uint32_t sl = threadIdx.x; sl < slots; sl += kClusterThreads) {
-        const uint32_t body = cluster_body[(size_t)cluster * slots + sl];
-        float4 a = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(etag)), b = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        if (body != 0xFFFFFFFFu) {
-            const float4 v0 = reinterpret_cast<const float4*>(vel)[2 * (size_t)body];
-            const float4 v1 = reinterpret_cast<const float4*>(vel)[2 * (size_t)body + 1];
-            a = make_float4(v0.x, v0.y, v0.z, __uint_as_float(etag));
-            b = make_float4(v1.x, v1.y, v1.z, v0.w);
-        }
-        s_vel[2 * sl] = a;
-        s_vel[2 * sl + 1] = b;
-    }
-    if (threadIdx.x <= (uint32_t)PHYS_MAX_COLORS) s_seg[threadIdx.x] = seg_start[(size_t)cluster * PHYS_MAX_COLORS + threadIdx.x];
-    __syncthreads();
-    const long long t_start = wall_clock64();
-    const bool side_b = (threadIdx.x & 1u) != 0u;
-    const uint32_t pair = threadIdx.x >> 1;
-    constexpr uint32_t kPairs = kClusterThreads / 2;
-    const v3 zero = v3_make(0.0f, 0.0f, 0.0f);
-    bool dead = false;
-    const uint32_t steps = iterations * n_colors;
-    uint32_t it = 0, col = 0;
-    for (uint32_t step = 0; step < steps; ++step) {
-        const bool last_it = it + 1 == iterations;
-        const uint32_t seg_lo = s_seg[col], seg_hi = s_seg[col + 1];
-        // pass count is the same for every lane of the workgroup (the DPP exchanges need both lanes of a pair, and a pair
-        // whose row index falls beyond the segment simply carries zeros)
-        for (uint32_t base = seg_lo; base < seg_hi; base += kPairs) {
-            const uint32_t d = base + pair;
-            const bool live = d < seg_hi;
-            const uint32_t dd = live ? d : seg_lo;  // a readable row for idle pairs (nothing of it is used)
-            // ---- this side's share of the row
-            const uint4 h = rows.hdr[dd];
-            const float4 nn = rows.n[dd];
-            const float4 t01 = rows.tb[dd], t23r = rows.tb[cap + dd];
-            float4 pr[4], ac[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                pr[k] = rows.pt[(size_t)(2 * k + (side_b ? 1 : 0)) * cap + dd];  // A: {rA, normal mass}  B: {rB, tangent mass 0}
-                ac[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                if (it != 0u) ac[k] = rows.acc[(size_t)k * cap + dd];  // written by this pair one iteration ago
-            }
-            const uint32_t count = live ? h.z : 0u;
-            const bool has_b = h.y != PHYS_GROUND_ID;
-            const uint32_t info = __float_as_uint(nn.w) >> (side_b ? 16 : 0);
-            const uint32_t slot = info & 0x1FFFu, mode = live ? ((info >> 14) & 3u) : 3u;
-            const bool pub = (info >> 13) & 1u;
-            const uint32_t body = side_b ? h.y : h.x;
-            const uint32_t tk = side_b ? (h.w >> 16) : h.w;
-            const uint32_t rank = tk & 0xFFu, deg = (tk >> 8) & 0xFFu;
-            const uint32_t ticket = it * deg + rank;
-            const bool final_update = last_it && rank + 1 == deg;
-            v3 dir[3];
-            dir[2] = v3_make(nn.x, nn.y, nn.z);
-            tangent_basis(dir[2], &dir[0], &dir[1]);
-            // masses and bias of every point, on both lanes: this side's plane carries one of the two packed masses
-            float nm[4], tm0[4], tm1[4], bias[4], pn[4], pt0[4], pt1[4];
-            v3 r[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float mine = pr[k].w, other = pair_swap(pr[k].w);
-                nm[k] = side_b ? other : mine;
-                tm0[k] = side_b ? mine : other;
-                const float4 t = k < 2 ? t01 : t23r;
-                tm1[k] = (k & 1) ? t.z : t.x;
-                bias[k] = (k & 1) ? t.w : t.y;
-                pn[k] = ac[k].x; pt0[k] = ac[k].y; pt1[k] = ac[k].z;
-                r[k] = v3_make(pr[k].x, pr[k].y, pr[k].z);
-            }
-            // ---- this side's body
-            v3 v = zero, w = zero;
-            float inv_m = 0.0f, mass = 0.0f;
-            bool need = false;
-            if (mode == 0u || mode == 1u) {
-                const float4 la = s_vel[2 * slot], lb = s_vel[2 * slot + 1];
-                v = v3_make(la.x, la.y, la.z); w = v3_make(lb.x, lb.y, lb.z); inv_m = lb.w;
-                if (mode == 1u) {
-                    need = __float_as_uint(la.w) != (etag | ticket);  // a remote row made the update before this one
-                    if (final_update) mass = vel[8 * (size_t)body + 7];
-                }
-            } else if (mode == 2u) {
-                const BodyVel B0 = ld_vel(vel, body);  // the state itself for ticket 0, the masses always
-                v = B0.v; w = B0.w; inv_m = B0.inv_mass; mass = B0.mass;
-                need = ticket != 0u;
-            }
-            uint32_t sweeps = 0;
-            while (need) {
-                const u32x4c g0 = ld_gran(rv, body * 32u), g1 = ld_gran(rv, body * 32u + 16u);
-                if (g0.w == (etag | ticket) && g1.w == (etag | ticket)) {
-                    v = v3_make(__uint_as_float(g0.x), __uint_as_float(g0.y), __uint_as_float(g0.z));
-                    w = v3_make(__uint_as_float(g1.x), __uint_as_float(g1.y), __uint_as_float(g1.z));
-                    need = false;
-                } else {
-                    __builtin_amdgcn_s_sleep(8);
-                    if ((++sweeps & 63u) == 0u) {
-                        const bool gone = (wall_clock64() - t_start > timeout_ticks) ||
-                                          (__hip_atomic_load(&ctr->overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 16u);
-                        if (gone) { flag_overflow(ctr, 16u); dead = true; need = false; }
-                    }
-                }
-            }
-            // a pair acts only when both of its lanes have their body; every lane reaches the exchanges below
-            const uint32_t pair_dead = (dead ? 1u : 0u) | pair_swap_u(dead ? 1u : 0u);
-            const bool has_body = mode != 3u;
-            m33 I;
-#pragma unroll
-            for (int k = 0; k < 9; ++k) I.m[k] = 0.0f;
-            if (has_body) I = ld_inertia_c<DIAG>(inv_inertia, body * inertia_stride);
-            v3 lin[3];  // lA / lB of the spec: dir * inverse mass (zero for a side without a body)
-#pragma unroll
-            for (int t = 0; t < 3; ++t) lin[t] = has_body ? v3_scale(dir[t], inv_m) : zero;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                if (k < (int)count) {  // the same for both lanes of the pair
-#pragma unroll
-                    for (int t = 0; t < 3; ++t) {
-                        // jac_row_make: a = r x dir, m = I a (zero for a side without a body)
-                        const v3 a = has_body ? v3_cross(r[k], dir[t]) : zero;
-                        const v3 mI = has_body ? m33_mul_v3(&I, a) : zero;
-                        // row_velocity: ub - ua with ua = dir.vA + aA.wA, ub = has_b ? dir.vB + aB.wB : 0
-                        const float mine = has_body ? v3_dot(dir[t], v) + v3_dot(a, w) : 0.0f;
-                        const float other = pair_swap(mine);
-                        const float vrel = side_b ? mine - other : other - mine;
-                        float lambda;
-                        if (t < 2) {  // solve_row_dir, friction
-                            const float tm = t == 0 ? tm0[k] : tm1[k];
-                            float& accu = t == 0 ? pt0[k] : pt1[k];
-                            lambda = -tm * vrel;
-                            const float maxf = friction * pn[k];
-                            const float old = accu;
-                            const float np = det_maxf(-maxf, det_minf(old + lambda, maxf));
-                            lambda = np - old;
-                            accu = np;
-                        } else {      // normal
-                            lambda = nm[k] * (bias[k] - vrel);
-                            const float old = pn[k];
-                            const float np = det_maxf(old + lambda, 0.0f);
-                            lambda = np - old;
-                            pn[k] = np;
-                        }
-                        // row_apply: A subtracts, B adds
-                        if (has_body) {
-                            if (side_b) { v = v3_add(v, v3_scale(lin[t], lambda)); w = v3_add(w, v3_scale(mI, lambda)); }
-                            else        { v = v3_sub(v, v3_scale(lin[t], lambda)); w = v3_sub(w, v3_scale(mI, lambda)); }
-                        }
-                    }
-                }
-            }
-            // ---- write back
-            if (live && !pair_dead) {
-                if (mode == 0u || mode == 1u) {
-                    s_vel[2 * slot] = make_float4(v.x, v.y, v.z, __uint_as_float(etag | (ticket + 1u)));
-                    s_vel[2 * slot + 1] = make_float4(w.x, w.y, w.z, inv_m);
-                }
-                if (mode == 1u || mode == 2u) {
-                    if (final_update) { BodyVel o; o.v = v; o.inv_mass = inv_m; o.w = w; o.mass = mass; st_vel(vel, body, o); }
-                    else if (mode == 2u || pub) { st_gran(rv, body * 32u, v, etag | (ticket + 1u)); st_gran(rv, body * 32u + 16u, w, etag | (ticket + 1u)); }
-                }
-                if (!last_it) {  // the A lane keeps the impulses of points 0 and 1, the B lane those of 2 and 3
-#pragma unroll
-                    for (int k = 0; k < 4; ++k)
-                        if (k < (int)count && ((k >> 1) == (side_b ? 1 : 0)))
-                            rows.acc[(size_t)k * cap + d] = make_float4(pn[k], pt0[k], pt1[k], 0.0f);
-                }
-            }
-        }
-        __syncthreads();  // LDS velocities of this colour are in place before the next colour reads them
-        if (++col == n_colors) { col = 0u; ++it; }
-    }
-    for (uint32_t sl = threadIdx.x; sl < slots; sl += kClusterThreads) {
-        const uint32_t body = cluster_body[(size_t)cluster * slots + sl];
-        if (body == 0xFFFFFFFFu || (body_shared[2 * (size_t)body] | body_shared[2 * (size_t)body + 1])) continue;
-        const float4 a = s_vel[2 * sl], b = s_vel[2 * sl + 1];
-        float4* out = reinterpret_cast<float4*>(vel) + 2 * (size_t)body;
-        const float mass = out[1].w;
-        out[0] = make_float4(a.x, a.y, a.z, b.w);
-        out[1] = make_float4(b.x, b.y, b.z, mass);
-    }
-}
-
-void launch_solve_cluster(phys_world* w, void* hdr, void* nrm, void* pt, void* tb, void* acc, uint64_t cap, float friction,
-                          const float* inertia, uint32_t stride, bool diag, long long timeout_ticks) {
+void launch_solve_cluster(phys_world* w, void* row_all, uint64_t cap, float friction, const float* inertia, uint32_t stride,
+                          bool diag, long long timeout_ticks) {
     static const uint32_t ablate = getenv("PHYS_DEBUG_ABLATE") ? (uint32_t)atoi(getenv("PHYS_DEBUG_ABLATE")) : 0u;
     ClusterRowArrays rows;
-    rows.hdr = (uint4*)hdr; rows.n = (float4*)nrm; rows.pt = (float4*)pt; rows.tb = (float4*)tb; rows.acc = (float4*)acc; rows.cap = cap;
-    const size_t lds = (size_t)w->cluster_slots * 32 + (PHYS_MAX_COLORS + 1) * 4 + 12;
+    rows.all = (float4*)row_all; rows.cap = cap;
+    const size_t lds = cluster_lds_bytes(w->cluster_slots);
     static bool attr_set[2] = {false, false};
     if (!attr_set[diag ? 1 : 0]) {  // more than the default 64 KiB of dynamic LDS needs the attribute (once per kernel)
         if (diag) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_solve_cluster<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -598,26 +450,14 @@ void launch_solve_cluster(phys_world* w, void* hdr, void* nrm, void* pt, void* t
         attr_set[diag ? 1 : 0] = true;
     }
     const dim3 g(w->cluster_count), b(kClusterThreads);
-    if (w->cluster_pair) {
-        static bool pair_attr = false;
-        if (!pair_attr) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_solve_cluster_pair<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            (void)hipGetLastError();
-            pair_attr = true;
-        }
-        hipLaunchKernelGGL(k_solve_cluster_pair<true>, g, b, lds, w->stream, w->counters.p, w->cfg.solver_iterations, w->flow_epoch, rows,
-                           friction, inertia, stride, w->vel.p, w->flow_vel.p, (uint32_t)w->n, w->cluster_body.p, w->body_shared.p,
-                           w->seg_start.p, w->cluster_slots, timeout_ticks);
-        return;
-    }
     if (diag)
         hipLaunchKernelGGL(k_solve_cluster<true>, g, b, lds, w->stream, w->counters.p, w->cfg.solver_iterations, w->flow_epoch, rows, friction,
-                           inertia, stride, w->vel.p, w->flow_vel.p, (uint32_t)w->n, w->cluster_body.p, w->body_shared.p, w->seg_start.p,
-                           w->cluster_slots, timeout_ticks, ablate);
+                           inertia, stride, w->vel.p, w->pos.p, w->flow_vel.p, (uint32_t)w->n, w->cluster_body.p, w->body_shared.p,
+                           w->seg_start.p, w->cluster_slots, timeout_ticks, ablate);
     else
         hipLaunchKernelGGL(k_solve_cluster<false>, g, b, lds, w->stream, w->counters.p, w->cfg.solver_iterations, w->flow_epoch, rows, friction,
-                           inertia, stride, w->vel.p, w->flow_vel.p, (uint32_t)w->n, w->cluster_body.p, w->body_shared.p, w->seg_start.p,
-                           w->cluster_slots, timeout_ticks, ablate);
+                           inertia, stride, w->vel.p, w->pos.p, w->flow_vel.p, (uint32_t)w->n, w->cluster_body.p, w->body_shared.p,
+                           w->seg_start.p, w->cluster_slots, timeout_ticks, ablate);
 }
 
 }  // namespace phys

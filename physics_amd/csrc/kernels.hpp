@@ -137,8 +137,8 @@ int32_t halo_pairs(phys_world* w, const void* dev_remote, uint64_t n_remote, uin
 int32_t cluster_assign(phys_world* w, const float* host_pos);
 void launch_cluster_sort(phys_world* w, unsigned blocks);
 void launch_exclusive_scan(phys_world* w, const uint32_t* in, uint32_t count, uint32_t* out);  // broadphase.hip; count % 4 == 0
-void launch_solve_cluster(phys_world* w, void* hdr, void* n, void* pt, void* tb, void* acc, uint64_t cap, float friction,
-                          const float* inertia, uint32_t stride, bool diag, long long timeout_ticks);
+void launch_solve_cluster(phys_world* w, void* row_all, uint64_t cap, float friction, const float* inertia, uint32_t stride,
+                          bool diag, long long timeout_ticks);
 
 int32_t halo_pack_bodies(phys_world* w, void* dev_out, uint64_t cap);
 int32_t halo_unpack_ghosts(phys_world* w, const void* dev_records, uint64_t n_records, uint64_t skip_first, uint64_t skip_count);

@@ -98,17 +98,6 @@ __global__ __launch_bounds__(256) void k_rows_build(const StepCounters* __restri
             g.depth[k] = p.w;
         }
         const int has_b = b != PHYS_GROUND_ID;
-        // DIAG: 16 bytes per body instead of 36 (and none at all when every body shares one tensor: stride 0);
-        // the zero off-diagonals are put back, so solver_prep's arithmetic is the general path's
-        const m33 IA = ld_inertia<DIAG>(inv_inertia, a * inertia_stride);
-        m33 IB;
-#pragma unroll
-        for (int k = 0; k < 9; ++k) IB.m[k] = 0.0f;
-        float imb = 0.0f;
-        v3 xB = v3_make(0.0f, 0.0f, 0.0f);
-        if (has_b) { IB = ld_inertia<DIAG>(inv_inertia, b * inertia_stride); imb = vel[8 * (size_t)b + 3]; xB = ld3(pos, b); }
-        solver_manifold_t sm;
-        solver_prep(&g, has_b, ld3(pos, a), xB, vel[8 * (size_t)a + 3], &IA, imb, &IB, &sp, &sm);
         uint32_t ticket = 0;
         if (flow) {
             // the colours in use at a body are exactly the colours of its manifolds (all distinct), so the rank of
@@ -122,7 +111,7 @@ __global__ __launch_bounds__(256) void k_rows_build(const StepCounters* __restri
             }
             if (flow == 2 && d == 0) ticket += 1;  // fault injection (PHYS_DEBUG_FLOW_STALL): row 0 waits for a turn that never comes
         }
-        rows.hdr[d] = make_uint4(a, b, (uint32_t)sm.count, ticket);
+        rows.hdr[d] = make_uint4(a, b, (uint32_t)g.count, ticket);
         uint32_t info = 0;
         if (cluster_slots) {
             // cluster solver (cluster.hip): where each side's velocity lives. Per side: slot (13 bits) | publish (1) |
@@ -164,7 +153,34 @@ __global__ __launch_bounds__(256) void k_rows_build(const StepCounters* __restri
             }
             info |= ib << 16;
         }
-        rows.n[d] = make_float4(sm.n.x, sm.n.y, sm.n.z, __uint_as_float(info));
+        rows.n[d] = make_float4(g.normal.x, g.normal.y, g.normal.z, __uint_as_float(info));
+        if (cluster_slots) {
+            // compact rows of the cluster solver (cluster.hip): the contact points themselves and the bias; lever arms and
+            // row masses are remade there from the body positions it keeps in LDS. Nothing of the bodies is read here.
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (k < g.count)
+                    rows.all[(size_t)(2 + k) * cap + d] = make_float4(g.pt[k].x, g.pt[k].y, g.pt[k].z, contact_bias(g.depth[k], &sp));
+            if (((info >> 30) & 3u) == 2u) {
+                // body B belongs to another cluster: what does not change during the solve rides with the row (planes 12,
+                // 13), or fetching it by body id would be a second dependent round trip in every colour step of the solver
+                const v3 xb = ld3(pos, b);
+                rows.all[(size_t)12 * cap + d] = make_float4(xb.x, xb.y, xb.z, vel[8 * (size_t)b + 3]);
+                if (DIAG) rows.all[(size_t)13 * cap + d] = reinterpret_cast<const float4*>(inv_inertia)[b * inertia_stride];
+            }
+            continue;
+        }
+        // DIAG: 16 bytes per body instead of 36 (and none at all when every body shares one tensor: stride 0);
+        // the zero off-diagonals are put back, so solver_prep's arithmetic is the general path's
+        const m33 IA = ld_inertia<DIAG>(inv_inertia, a * inertia_stride);
+        m33 IB;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) IB.m[k] = 0.0f;
+        float imb = 0.0f;
+        v3 xB = v3_make(0.0f, 0.0f, 0.0f);
+        if (has_b) { IB = ld_inertia<DIAG>(inv_inertia, b * inertia_stride); imb = vel[8 * (size_t)b + 3]; xB = ld3(pos, b); }
+        solver_manifold_t sm;
+        solver_prep(&g, has_b, ld3(pos, a), xB, vel[8 * (size_t)a + 3], &IA, imb, &IB, &sp, &sm);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             if (k < sm.count) {
@@ -628,7 +644,7 @@ __global__ __launch_bounds__(256) void k_solve_flow_quad(StepCounters* __restric
                             // solver_jacobians: lA = dir * invM; aA = r x dir, mA = I aA. The A side is subtracted
                             // by the spec: its response is stored negated (exact)
                             v3 jv, rs;
-                            if (angular) { jv = v3_cross(r, dir[t]); rs = m33_mul_v3(&I, jv); }
+                            if (angular) { jv = v3_cross(r, dir[t]); rs = inertia_mul(&I, jv); }
                             else { jv = dir[t]; rs = v3_scale(dir[t], inv_m); }
                             Jv[k][t] = jv;
                             Rs[k][t] = side_a ? v3_neg(rs) : rs;
@@ -838,7 +854,7 @@ __global__ __launch_bounds__(256) void k_solve_color_quad(StepCounters* ctr, uin
                             // solver_jacobians: lA = dir * invM; aA = r x dir, mA = I aA; the A side is subtracted by
                             // the spec, so its response is stored negated (exact)
                             v3 jv, rs;
-                            if (angular) { jv = v3_cross(rr, dir[t]); rs = m33_mul_v3(&I, jv); }
+                            if (angular) { jv = v3_cross(rr, dir[t]); rs = inertia_mul(&I, jv); }
                             else { jv = dir[t]; rs = v3_scale(dir[t], inv_m); }
                             Jv[k][t] = jv;
                             Rs[k][t] = side_a ? v3_neg(rs) : rs;
@@ -973,7 +989,7 @@ void launch_solver(phys_world* w, float dt) {
         }
         if (cluster) {
             PHYS_PROF(w, PHYS_STAGE_SOLVE_CLUSTER);
-            launch_solve_cluster(w, rows.hdr, rows.n, rows.pt, rows.tb, rows.acc, cap, sp.friction, inertia, stride, diag, timeout_ticks);
+            launch_solve_cluster(w, rows.all, cap, sp.friction, inertia, stride, diag, timeout_ticks);
             return;
         }
         // about one wave per SIMD or less: waiting waves must not crowd out the ones that can run

@@ -18,7 +18,7 @@ namespace phys {
 constexpr int kMaxColors = 64;  // == PHYS_MAX_COLORS of include/spec/contact_solve.h
 constexpr uint64_t kClusterMinBodies = 32768;  // below: the dataflow kernels win anyway (few launches' worth of rows)
 constexpr uint64_t kClusterMinManifolds = 300000;  // fewer rows: the single-launch dataflow kernel (measured crossover)
-constexpr uint32_t kClusterMaxSlots = 4608;    // bodies per cluster whose {v, w} fit one CU's LDS (32 B each: 144 KiB; 13-bit slot field)
+constexpr uint32_t kClusterMaxSlots = 2496;    // bodies per cluster whose {v, w, x, I^-1} fit one CU's LDS (64 B each: 156 KiB; 13-bit slot field)
 
 void set_error(const std::string& msg);
 const char* get_error();
@@ -244,7 +244,6 @@ struct phys_world {
     // cluster solver (cluster.hip): spatial clusters fixed at phys_set_bodies, rows sorted by (cluster, colour) per step
     uint32_t cluster_count = 0, cluster_slots = 0;  // 0 clusters: not available for this scene
     bool cluster_step = false;                      // this update's rows are in (cluster, colour) order
-    bool cluster_pair = false;                      // k_solve_cluster_pair (two lanes per row) instead of k_solve_cluster
     phys::DevBuf<uint32_t> cluster_slot;   // body -> cluster * slots + slot
     phys::DevBuf<uint32_t> cluster_body;   // cluster * slots + slot -> body (0xFFFFFFFF: empty)
     phys::DevBuf<uint32_t> body_shared;    // 2 per body: 64-bit mask of the colours in which ANOTHER cluster's row updates it

@@ -28,6 +28,12 @@ VARIANTS = {
     "cl_nocompute": {"PHYS_DEBUG_CLUSTER_MIN": "0", "PHYS_DEBUG_ABLATE": "2"},  # timing only
     "cl_bare": {"PHYS_DEBUG_CLUSTER_MIN": "0", "PHYS_DEBUG_ABLATE": "10"},      # timing only: neither
     "default": {},
+    "cl_norot": {"PHYS_DEBUG_ABLATE": "16"},    # same bits: rows always start on wave 0
+    "cl_remass": {"PHYS_DEBUG_ABLATE": "32"},   # same bits: row masses remade in every iteration
+    "cl_norot_remass": {"PHYS_DEBUG_ABLATE": "48"},
+    "cluster2": {"PHYS_DEBUG_CLUSTERS_PER_CU": "2"},
+    "cl_allcus": {"PHYS_DEBUG_CLUSTER_SPARE": "0"},
+    "cl_spare16": {"PHYS_DEBUG_CLUSTER_SPARE": "16"},
     # timing diagnosis of the one-lane per-colour kernel (results are WRONG by construction: hashes differ)
     "nogather": dict(NC, PHYS_DEBUG_COLOR_KERNEL="lane", PHYS_DEBUG_FLOW_MAX="0", PHYS_DEBUG_ABLATE="1"),
     "nocompute": dict(NC, PHYS_DEBUG_COLOR_KERNEL="lane", PHYS_DEBUG_FLOW_MAX="0", PHYS_DEBUG_ABLATE="2"),
