@@ -560,7 +560,7 @@ int32_t collision_alloc(phys_world* w) {
         {
             uint64_t cap = 4096;
             while (cap < M + M / 2) cap <<= 1;
-            for (int t = 0; t < 2; ++t) { PHYS_HIP_TRY(w->ctab_keys[t].resize(cap)); PHYS_HIP_TRY(w->ctab_cols[t].resize(cap)); PHYS_HIP_TRY(w->ctab_slots[t].resize(M + 1)); w->ctab_fresh[t] = false; }
+            PHYS_HIP_TRY(w->ctab.resize(2 * cap));
             w->ctab_mask = (uint32_t)(cap - 1);
             w->ctab_valid = false;
             w->color_epoch = 0;

@@ -66,36 +66,42 @@ __device__ __forceinline__ m33 ld_inertia_c(const float* __restrict__ p, uint32_
     return M;
 }
 
-// Persistent colouring: hash table (a << 32 | b) -> colour of this update's manifolds, looked up by the next
-// update's narrow phase. Open addressing, linear probing; the table has at least 1.5 slots per manifold SLOT of the
-// world, so an insert always finds room. The layout depends on arrival order, the answers (exact key matches) do
-// not. The job rides along in k_rows_build (launch_coloring fills it in, launch_solver hands it over).
+// Persistent colouring: ONE hash table (a << 32 | b) -> {colour, update stamp} that lives across updates. Open addressing,
+// linear probing, 16-byte entries {key, stamp << 32 | colour}; at least 1.5 slots per manifold SLOT of the world.
+//   * the narrow phase of update E looks every manifold up: an exact key match whose stamp is E - 1 ("was there in the
+//     previous update") keeps its colour and is re-stamped E on the spot - one 8-byte store to the line the probe has
+//     just read. Entries that are not re-stamped are dead from then on.
+//   * k_rows_build inserts only the manifolds that were NEW in this update (a few per cent of a steady pile), into the
+//     first slot of their chain that is not live: claimed by a 64-bit CAS on the VALUE word (stamp becomes E), key stored
+//     after. A slot stamped E is nobody else's business, whatever key it shows, so a half-written claim is never
+//     taken for a match; pairs are unique within an update, so nobody looks for a key stamped E.
+//   * a key's live entry is always the first entry of that key in its chain (a dead one before it would have been
+//     reused by the insert), chains never shrink (slots go back to empty only in the reset), so a probe may stop at the
+//     first empty slot or the first entry with its key.
+//   * every PHYS_COLOR_CACHE_PERIOD-th update (nothing is kept then anyway) the table is reset by one memset.
+// Round 1-2a rebuilt a table per update inside k_rows_build (an atomic and two scattered stores per manifold, plus the
+// sparse clear of the other table): 0.26 of k_rows_build's 0.50 ms on C5. The layout depends on arrival order, the
+// answers (exact key + stamp matches) do not.
 struct ColorTableJob {
-    unsigned long long* keys;        // null: nothing to do
-    uint32_t* cols;
+    ulonglong2* tab;  // null: nothing to do
     uint32_t mask;
-    uint32_t* slots;                 // [0] = count, then the slot of every manifold (sparse clear two updates later)
-    unsigned long long* other_keys;  // the table the narrow phase of THIS update read: emptied here (null: not yet used)
-    const uint32_t* other_slots;
-    const uint32_t* man_a; const uint32_t* man_b; const uint32_t* man_color; const uint64_t* man_prio;
+    uint32_t stamp;   // of the update whose manifolds are being inserted
+    const uint32_t* man_color; const uint64_t* man_prio;
 };
 
-__device__ __forceinline__ void color_table_update(const ColorTableJob& job, uint32_t M) {
-    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x, nthreads = gridDim.x * blockDim.x;
-    if (job.other_keys) {
-        // revisit exactly the slots the last build filled: no memset of a capacity-sized table, no extra launch
-        const uint32_t count = job.other_slots[0];
-        for (uint32_t i = tid; i < count; i += nthreads) job.other_keys[job.other_slots[1 + i]] = ~0ull;
-    }
-    if (tid == 0) job.slots[0] = M;
-    for (uint32_t m = tid; m < M; m += nthreads) {
-        const unsigned long long key = ((unsigned long long)job.man_a[m] << 32) | job.man_b[m];
-        uint32_t h = (uint32_t)(job.man_prio[m] >> 20) & job.mask;
-        for (;;) {
-            const unsigned long long prev = atomicCAS(&job.keys[h], ~0ull, key);
-            if (prev == ~0ull || prev == key) { job.cols[h] = job.man_color[m]; job.slots[1 + m] = h; break; }
-            h = (h + 1) & job.mask;
+__device__ __forceinline__ void color_table_insert(const ColorTableJob& job, uint32_t a, uint32_t b, uint32_t m) {
+    const unsigned long long key = ((unsigned long long)a << 32) | b;
+    const unsigned long long val = ((unsigned long long)job.stamp << 32) | job.man_color[m];
+    uint32_t h = (uint32_t)(job.man_prio[m] >> 20) & job.mask;
+    for (;;) {
+        unsigned long long* vp = &job.tab[h].y;
+        const unsigned long long seen = __hip_atomic_load(vp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((uint32_t)(seen >> 32) != job.stamp && atomicCAS(vp, seen, val) == seen) {
+            job.tab[h].x = key;
+            return;
         }
+        if ((uint32_t)(__hip_atomic_load(vp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32) == job.stamp) h = (h + 1) & job.mask;
+        // else: somebody else's CAS on a dead slot failed too, or the value changed under us - look at the slot again
     }
 }
 

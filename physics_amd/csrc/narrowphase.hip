@@ -39,8 +39,8 @@ __global__ __launch_bounds__(kNpThreads) void k_narrowphase(
     uint64_t max_manifolds, uint32_t* __restrict__ man_a, uint32_t* __restrict__ man_b,
     uint32_t* __restrict__ man_color, float* __restrict__ man_geo /* 32 floats per manifold */,
     uint64_t* __restrict__ man_prio, unsigned long long* __restrict__ used,
-    unsigned long long* __restrict__ top0, const unsigned long long* __restrict__ cache_keys,
-    const uint32_t* __restrict__ cache_cols, uint32_t cache_mask /* 0 = keep nothing this update */,
+    unsigned long long* __restrict__ top0, ulonglong2* __restrict__ cache /* persistent colour table (kernels.hpp) */,
+    uint32_t cache_mask /* 0 = keep nothing this update */, uint32_t stamp /* of this update */,
     StepCounters* __restrict__ ctr) {
     __shared__ uint32_t wcount[kNpThreads / 64], wpts[kNpThreads / 64], wground[kNpThreads / 64], wunc[kNpThreads / 64];
     __shared__ uint32_t block_base;
@@ -114,16 +114,22 @@ __global__ __launch_bounds__(kNpThreads) void k_narrowphase(
                 man_b[slot] = b;
                 const unsigned long long prio = color_priority(a, b);
                 man_prio[slot] = prio;
-                // persistent colouring (contact_solve.h): a manifold that existed in the previous update keeps
-                // its colour - exact 64-bit key match in the hash table built at the end of that update
+                // persistent colouring (contact_solve.h): a manifold that existed in the previous update keeps its
+                // colour - exact 64-bit key match in the table, stamped by the previous update; re-stamped here
                 uint32_t col = kUncolored;
                 if (cache_mask) {
                     const unsigned long long key = ((unsigned long long)a << 32) | b;
                     uint32_t h = (uint32_t)(prio >> 20) & cache_mask;
                     for (;;) {
-                        const unsigned long long kk = cache_keys[h];
-                        if (kk == key) { col = cache_cols[h]; break; }
-                        if (kk == ~0ull) break;  // empty slot: not in the previous update
+                        const ulonglong2 e = cache[h];
+                        if (e.x == key) {
+                            if ((uint32_t)(e.y >> 32) + 1u == stamp) {
+                                col = (uint32_t)e.y;
+                                cache[h].y = ((unsigned long long)stamp << 32) | col;
+                            }
+                            break;  // a dead entry of this key: no live one follows
+                        }
+                        if (e.x == ~0ull) break;  // empty slot: never seen
                         h = (h + 1) & cache_mask;
                     }
                 }
@@ -143,7 +149,8 @@ __global__ __launch_bounds__(kNpThreads) void k_narrowphase(
                     if (b != PHYS_GROUND_ID) atomicMax(&top0[b], prio);
                 }
                 float4* o = reinterpret_cast<float4*>(man_geo) + 8 * slot;  // one 128-byte line per manifold, 96 bytes used
-                o[0] = make_float4(__uint_as_float(a), __uint_as_float(b), __uint_as_float((uint32_t)m.count), 0.0f);
+                o[0] = make_float4(__uint_as_float(a), __uint_as_float(b), __uint_as_float((uint32_t)m.count),
+                                   __uint_as_float(col != kUncolored ? 1u : 0u) /* colour kept: already in the table */);
                 o[1] = make_float4(m.normal.x, m.normal.y, m.normal.z, 0.0f);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) o[2 + k] = make_float4(m.pt[k].x, m.pt[k].y, m.pt[k].z, m.depth[k]);
@@ -582,9 +589,9 @@ void launch_narrowphase(phys_world* w) {
     const uint64_t work = (uint64_t)n_ground + w->max_pairs;
     // colouring state of the step: used masks + three rotating priority buffers (one memset); the narrow
     // phase publishes round 0's per-body maxima as it emits manifolds
-    // persistent colouring: table of the previous update, unless this is a re-compaction update
-    const uint32_t prev_tab = (uint32_t)((w->color_epoch + 1) & 1);
+    // persistent colouring: colours of the previous update are kept, unless this is a re-compaction update
     const uint32_t cache_mask = (w->color_epoch % PHYS_COLOR_CACHE_PERIOD) != 0 && w->ctab_valid ? w->ctab_mask : 0u;
+    const uint32_t stamp = (uint32_t)w->color_epoch + 1u;  // never 0xFFFFFFFF (the stamp of an empty slot) in a world's life
     PHYS_PROF(w, PHYS_STAGE_NARROW);
 #define PHYS_NP_LAUNCH(T)                                                                                              \
     do {                                                                                                               \
@@ -594,8 +601,8 @@ void launch_narrowphase(phys_world* w) {
                            w->max_pairs, w->pos.p, w->rot.p, w->half_extent.p, w->shape.p, w->cfg.contact_margin,      \
                            w->cfg.ground_height, w->max_manifolds, w->man_a.p, w->man_b.p,                             \
                            w->man_color.p, w->man_geo.p, w->man_prio.p, w->color_state.p,                              \
-                           w->color_state.p + n, (const unsigned long long*)w->ctab_keys[prev_tab].p,                  \
-                           w->ctab_cols[prev_tab].p, cache_mask, w->counters.p);                                       \
+                           w->color_state.p + n, reinterpret_cast<ulonglong2*>(w->ctab.p), cache_mask, stamp,          \
+                           w->counters.p);                                                                             \
     } while (0)
     if (n <= 200000u) PHYS_NP_LAUNCH(128); else PHYS_NP_LAUNCH(256);
 #undef PHYS_NP_LAUNCH
@@ -685,17 +692,13 @@ void launch_coloring(phys_world* w) {
     else { PHYS_PROF(w, PHYS_STAGE_ROWS); hipLaunchKernelGGL(k_color_place, dim3(nb), dim3(1024), 0, s, w->max_manifolds, w->man_color.p, w->color_block_hist.p, nb, w->row_src.p, w->counters.p); }
     }
     {
-        // colour table of this update for the next one (the slot it overwrites was read two updates ago)
-        const uint32_t tab = (uint32_t)(w->color_epoch & 1);
-        if (!w->ctab_fresh[tab]) {
+        // the new manifolds of this update go into the colour table in k_rows_build (launch_solver): one launch less
+        if (full) {  // nothing was kept: start from an empty table (this also purges the dead entries of the period)
             PHYS_PROF(w, PHYS_STAGE_ROWS);
-            (void)hipMemsetAsync(w->ctab_keys[tab].p, 0xFF, ((size_t)w->ctab_mask + 1) * 8, s);  // first use of this table
-            w->ctab_fresh[tab] = true;
+            (void)hipMemsetAsync(w->ctab.p, 0xFF, ((size_t)w->ctab_mask + 1) * 16, s);
         }
-        // the build itself rides along in k_rows_build (launch_solver): one launch less per step
         w->ctab_job_pending = true;
-        w->ctab_job_tab = tab;
-        w->ctab_job_clear_other = w->ctab_fresh[tab ^ 1u];  // it holds the previous update's entries
+        w->ctab_job_stamp = (uint32_t)w->color_epoch + 1u;
         w->ctab_valid = true;
         w->color_epoch++;
     }

@@ -72,14 +72,6 @@ __global__ __launch_bounds__(256) void k_rows_build(const StepCounters* __restri
                                                     ColorTableJob table, const uint32_t* __restrict__ cluster_slot,
                                                     const uint32_t* __restrict__ body_shared,
                                                     uint32_t cluster_slots /* 0: not a cluster-solver step */) {
-    {
-        // colour table for the next update's narrow phase: built even when the solve is skipped, or the update after
-        // an overflow would keep colours from a table two updates old
-        // ... but an improper colouring (colour overflow, bit 2) must not be inherited: the table is then built EMPTY
-        // and the next update colours everything from scratch
-        const uint32_t raw = (ctr->overflow & 4u) ? 0u : ctr->n_manifolds;
-        if (table.keys) color_table_update(table, (uint64_t)raw < rows.cap ? raw : (uint32_t)rows.cap);
-    }
     if (ctr->overflow) return;  // never solve a truncated set; phys_sync / phys_get_stats report it
     const uint32_t M = ctr->n_manifolds;
     const uint64_t cap = rows.cap;
@@ -98,6 +90,8 @@ __global__ __launch_bounds__(256) void k_rows_build(const StepCounters* __restri
             g.depth[k] = p.w;
         }
         const int has_b = b != PHYS_GROUND_ID;
+        // persistent colouring: a manifold that is new in this update enters the colour table (kernels.hpp)
+        if (table.tab && __float_as_uint(r0.w) == 0u) color_table_insert(table, a, b, m);
         uint32_t ticket = 0;
         if (flow) {
             // the colours in use at a body are exactly the colours of its manifolds (all distinct), so the rank of
@@ -960,14 +954,10 @@ void launch_solver(phys_world* w, float dt) {
     const long long timeout_ticks = stall ? 2000000ll : kFlowTimeoutTicks;
     ColorTableJob table{};
     if (w->ctab_job_pending) {
-        const uint32_t tab = w->ctab_job_tab, other = tab ^ 1u;
-        table.keys = (unsigned long long*)w->ctab_keys[tab].p;
-        table.cols = w->ctab_cols[tab].p;
+        table.tab = reinterpret_cast<ulonglong2*>(w->ctab.p);
         table.mask = w->ctab_mask;
-        table.slots = w->ctab_slots[tab].p;
-        table.other_keys = w->ctab_job_clear_other ? (unsigned long long*)w->ctab_keys[other].p : nullptr;
-        table.other_slots = w->ctab_slots[other].p;
-        table.man_a = w->man_a.p; table.man_b = w->man_b.p; table.man_color = w->man_color.p; table.man_prio = w->man_prio.p;
+        table.stamp = w->ctab_job_stamp;
+        table.man_color = w->man_color.p; table.man_prio = w->man_prio.p;
         w->ctab_job_pending = false;
     }
     { PHYS_PROF(w, PHYS_STAGE_ROWS);

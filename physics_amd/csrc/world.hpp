@@ -214,16 +214,12 @@ struct phys_world {
     phys::DevBuf<float> man_geo;
     phys::DevBuf<uint64_t> man_prio;
     // persistent colouring: two hash tables (this update's / the previous update's), key -> colour
-    phys::DevBuf<uint64_t> ctab_keys[2];
-    phys::DevBuf<uint32_t> ctab_cols[2];
-    phys::DevBuf<uint32_t> ctab_slots[2];  // [0] = entries of the last build, then their slot numbers (sparse clear)
-    bool ctab_fresh[2] = {false, false};  // the table has been memset once and is maintained by sparse clears
+    phys::DevBuf<uint64_t> ctab;  // persistent colour table: 2 words per slot {key, stamp << 32 | colour} (kernels.hpp)
     uint32_t ctab_mask = 0;     // capacity - 1 (power of two >= 1.5 * max_manifolds)
     bool ctab_valid = false;    // a table of the previous update exists
     uint64_t color_epoch = 0;   // updates with collisions since phys_set_bodies
     bool ctab_job_pending = false;  // launch_coloring prepared a table build for launch_solver's k_rows_build
-    uint32_t ctab_job_tab = 0;      // which of the two tables it fills
-    bool ctab_job_clear_other = false;
+    uint32_t ctab_job_stamp = 0;    // the stamp its entries get
     phys::DevBuf<uint32_t> color_block_hist;  // [colour][workgroup] histogram / offsets of the colour sort
     // colouring state
     phys::DevBuf<unsigned long long> color_state;  // 4n: used masks | three rotating per-body priority buffers

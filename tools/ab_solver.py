@@ -32,6 +32,7 @@ VARIANTS = {
     "cl_remass": {"PHYS_DEBUG_ABLATE": "32"},   # same bits: row masses remade in every iteration
     "cl_norot_remass": {"PHYS_DEBUG_ABLATE": "48"},
     "cluster2": {"PHYS_DEBUG_CLUSTERS_PER_CU": "2"},
+    "no_ctab": {"PHYS_DEBUG_NO_CTAB": "1"},   # timing of the rows stage without the colour-table build (colours differ)
     "cl_allcus": {"PHYS_DEBUG_CLUSTER_SPARE": "0"},
     "cl_spare16": {"PHYS_DEBUG_CLUSTER_SPARE": "16"},
     # timing diagnosis of the one-lane per-colour kernel (results are WRONG by construction: hashes differ)
