@@ -170,7 +170,7 @@ int32_t phys_destroy(phys_world* w) {
     for (auto* b : ub) b->free();
     w->man_prio.free(); w->color_state.free(); w->bucket_count.free(); w->step_zero.free();
     w->d_constraints.free(); w->counters.free();
-    w->ctab.free();
+    w->ctab.free(); w->unc_list.free();
     w->prof.destroy();
     for (int k = 0; k < phys_world::kSnapRing; ++k) {
         if (w->h_snap[k]) (void)hipHostFree(w->h_snap[k]);

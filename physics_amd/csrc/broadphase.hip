@@ -557,6 +557,7 @@ int32_t collision_alloc(phys_world* w) {
         PHYS_HIP_TRY(w->man_geo.resize(32 * M));
         PHYS_HIP_TRY(w->man_prio.resize(M));
         PHYS_HIP_TRY(w->row_src.resize(M));
+        PHYS_HIP_TRY(w->unc_list.resize(2 * M));
         {
             uint64_t cap = 4096;
             while (cap < M + M / 2) cap <<= 1;

@@ -41,9 +41,10 @@ __global__ __launch_bounds__(kNpThreads) void k_narrowphase(
     uint64_t* __restrict__ man_prio, unsigned long long* __restrict__ used,
     unsigned long long* __restrict__ top0, ulonglong2* __restrict__ cache /* persistent colour table (kernels.hpp) */,
     uint32_t cache_mask /* 0 = keep nothing this update */, uint32_t stamp /* of this update */,
+    uint32_t* __restrict__ unc_list /* ids of the manifolds that did not keep a colour: round 0 of the colouring */,
     StepCounters* __restrict__ ctr) {
     __shared__ uint32_t wcount[kNpThreads / 64], wpts[kNpThreads / 64], wground[kNpThreads / 64], wunc[kNpThreads / 64];
-    __shared__ uint32_t block_base;
+    __shared__ uint32_t block_base, unc_base;
     // polygon-clipper scratch in LDS: one 56-dword slice per lane at an odd (57) dword stride, so the lanes of
     // a wave hit distinct banks; private scratch memory would go through L1/L2 instead
     constexpr int kWsStride = sizeof(clip_ws_t) / 4 + 1;
@@ -105,11 +106,13 @@ __global__ __launch_bounds__(kNpThreads) void k_narrowphase(
         }
         __syncthreads();
         bool uncolored = false;
+        uint32_t my_slot = 0;
         if (has) {
             uint32_t woff = 0;
             for (int k = 0; k < wave; ++k) woff += wcount[k];
             const uint64_t slot = (uint64_t)block_base + woff + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
             if (slot < max_manifolds) {
+                my_slot = (uint32_t)slot;
                 man_a[slot] = a;
                 man_b[slot] = b;
                 const unsigned long long prio = color_priority(a, b);
@@ -162,7 +165,16 @@ __global__ __launch_bounds__(kNpThreads) void k_narrowphase(
         if (threadIdx.x == 0) {
             uint32_t t = 0;
             for (int k = 0; k < kNpThreads / 64; ++k) t += wunc[k];
-            if (t) atomicAdd(&ctr->n_uncolored, t);  // wunc is rewritten only after two more barriers
+            if (t) {
+                atomicAdd(&ctr->n_uncolored, t);
+                unc_base = atomicAdd(&ctr->unc_count[0], t);  // this workgroup's stretch of the round-0 list
+            }
+        }
+        __syncthreads();  // (wunc is rewritten only after the next trip's first barrier)
+        if (uncolored) {
+            uint32_t at = unc_base + (uint32_t)__popcll(umask & ((1ull << lane) - 1ull));
+            for (int k = 0; k < wave; ++k) at += wunc[k];
+            unc_list[at] = my_slot;  // at < stored manifolds <= max_manifolds
         }
     }
 }
@@ -174,6 +186,7 @@ __device__ __forceinline__ uint32_t stored_manifolds(const StepCounters* ctr, ui
 }
 
 constexpr int kColorThreads = 1024;
+constexpr int kColorStage = 8192;  // losers of one workgroup and round staged in LDS (k_color_round)
 
 // Ordering between the waves of ONE workgroup that talk through global memory (single-workgroup colouring
 // kernels): every wave's stores and atomics have been performed at the L2 once its vmcnt has drained, and the
@@ -189,7 +202,10 @@ __device__ __forceinline__ void drain_stores_for_workgroup() { asm volatile("s_w
 //   top_clr  (store)  the buffer read one round ago, cleared at the losers' bodies for the round after next.
 // Round 0's `top` is filled by k_narrowphase at emission time.
 // body of one round for the manifolds m = first, first + stride, ...; returns this lane's wins
-template <bool BYPASS_L1>
+// AGG: `next_list` is a list in global memory shared by all workgroups of the launch. Same-address atomics serialise
+// chip-wide (~88 per microsecond), so the losers of a workgroup are staged in LDS (`stage`, one LDS atomic per wave and
+// trip) and the caller appends them with ONE global atomic; only what does not fit the stage goes out directly.
+template <bool BYPASS_L1, bool AGG = false>
 __device__ __forceinline__ uint32_t color_round_lanes(uint32_t first, uint32_t stride, uint32_t M,
                                                       const uint32_t* list /* null: every manifold; else M ids */,
                                                       uint32_t* next_list /* non-null: `list` holds uncoloured ids only, and
@@ -199,7 +215,8 @@ __device__ __forceinline__ uint32_t color_round_lanes(uint32_t first, uint32_t s
                                                       uint32_t* __restrict__ man_color, const uint64_t* __restrict__ man_prio,
                                                       const unsigned long long* top, unsigned long long* top_next,
                                                       unsigned long long* top_clr, unsigned long long* used,
-                                                      StepCounters* __restrict__ ctr) {
+                                                      StepCounters* __restrict__ ctr, uint32_t* stage = nullptr,
+                                                      uint32_t* stage_n = nullptr, uint32_t stage_cap = 0) {
     uint32_t wins = 0;
     for (uint32_t i = first; i < M; i += stride) {
         const uint32_t m = list ? list[i] : i;
@@ -207,6 +224,7 @@ __device__ __forceinline__ uint32_t color_round_lanes(uint32_t first, uint32_t s
         const unsigned long long p = man_prio[m];
         const uint32_t a = man_a[m], b = man_b[m];
         const bool gb = b == PHYS_GROUND_ID;
+        bool lose = false;
         // BYPASS_L1 (single-launch finish loop): words other waves changed with atomics inside this launch
         // must come from L2, not from a line this CU cached rounds ago
         const unsigned long long ta = BYPASS_L1 ? __hip_atomic_load(&top[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : top[a];
@@ -232,12 +250,27 @@ __device__ __forceinline__ uint32_t color_round_lanes(uint32_t first, uint32_t s
             man_color[m] = c;
             ++wins;
         } else {
-            if (next_list) next_list[atomicAdd(next_count, 1u)] = m;
+            lose = true;
+            if (next_list && !AGG) next_list[atomicAdd(next_count, 1u)] = m;
             atomicMax(&top_next[a], p);
             if (BYPASS_L1) __hip_atomic_store(&top_clr[a], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else top_clr[a] = 0ull;
             if (!gb) {
                 atomicMax(&top_next[b], p);
                 if (BYPASS_L1) __hip_atomic_store(&top_clr[b], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else top_clr[b] = 0ull;
+            }
+        }
+        if (AGG) {
+            const unsigned long long losers = __ballot(lose);
+            if (losers) {
+                const int lane = (int)(threadIdx.x & 63u), leader = __ffsll((long long)losers) - 1;
+                uint32_t base = 0;
+                if (lane == leader) base = atomicAdd(stage_n, (uint32_t)__popcll(losers));  // LDS
+                base = (uint32_t)__shfl((int)base, leader, 64);
+                if (lose) {
+                    const uint32_t at = base + (uint32_t)__popcll(losers & ((1ull << lane) - 1ull));
+                    if (at < stage_cap) stage[at] = m;
+                    else next_list[atomicAdd(next_count, 1u)] = m;  // the stage is full (a launch far smaller than its list)
+                }
             }
         }
     }
@@ -250,6 +283,9 @@ __device__ __forceinline__ uint32_t color_round_lanes(uint32_t first, uint32_t s
 //                     round publish their priority there (it was cleared one round ago);
 //   top_clr  (store)  the buffer read one round ago, cleared at the losers' bodies for the round after next.
 // Round 0's `top` is filled by k_narrowphase at emission time.
+// The round runs over the LIST of the manifolds that were uncoloured at its start (round 0: written by the narrow
+// phase; round r + 1: the losers of round r) - a steady pile has a few per cent of new manifolds per update, and
+// scanning the colours of all of them in every round was 7.4 us per launch on C5, twenty times per step.
 __global__ __launch_bounds__(kColorThreads) void k_color_round(uint32_t round, uint64_t max_manifolds,
                                                               const uint32_t* __restrict__ man_a,
                                                               const uint32_t* __restrict__ man_b,
@@ -259,17 +295,33 @@ __global__ __launch_bounds__(kColorThreads) void k_color_round(uint32_t round, u
                                                               unsigned long long* __restrict__ top_next,
                                                               unsigned long long* __restrict__ top_clr,
                                                               unsigned long long* __restrict__ used,
+                                                              const uint32_t* __restrict__ list, uint32_t* __restrict__ next_list,
                                                               StepCounters* __restrict__ ctr) {
-    // block-uniform early exit (other workgroups decrement n_uncolored while this one starts, so every
-    // thread must act on the SAME read: a barrier follows). A stale non-zero read costs an idle pass.
-    __shared__ uint32_t s_uncolored;
+    // block-uniform early exit (every thread must act on the SAME read: a barrier follows)
+    __shared__ uint32_t s_count;
     __shared__ uint32_t s_wins[kColorThreads / 64];
-    if (threadIdx.x == 0) s_uncolored = ctr->n_uncolored;
+    if (threadIdx.x == 0) {
+        const uint32_t c = ctr->unc_count[round % 3u];
+        s_count = (uint64_t)c < max_manifolds ? c : (uint32_t)max_manifolds;
+        // the counter read one round ago is appended to one round from now
+        if (blockIdx.x == 0) ctr->unc_count[(round + 2u) % 3u] = 0u;
+    }
     __syncthreads();
-    if (s_uncolored == 0) return;
-    const uint32_t M = stored_manifolds(ctr, max_manifolds);
-    uint32_t wins = color_round_lanes<false>(blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x, M, nullptr, nullptr, nullptr, man_a, man_b,
-                                             man_color, man_prio, top, top_next, top_clr, used, ctr);
+    const uint32_t count = s_count;
+    if (blockIdx.x * blockDim.x >= count) return;
+    __shared__ uint32_t s_stage[kColorStage];
+    __shared__ uint32_t s_stage_n, s_stage_base;
+    if (threadIdx.x == 0) s_stage_n = 0;
+    __syncthreads();
+    uint32_t* next_count = &ctr->unc_count[(round + 1u) % 3u];
+    uint32_t wins = color_round_lanes<false, true>(blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x, count, list, next_list,
+                                                   next_count, man_a, man_b, man_color, man_prio, top, top_next, top_clr, used, ctr,
+                                                   s_stage, &s_stage_n, (uint32_t)kColorStage);
+    __syncthreads();
+    const uint32_t staged = s_stage_n < (uint32_t)kColorStage ? s_stage_n : (uint32_t)kColorStage;
+    if (threadIdx.x == 0 && staged) s_stage_base = atomicAdd(next_count, staged);
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < staged; i += kColorThreads) next_list[s_stage_base + i] = s_stage[i];
     // ONE global atomic per workgroup (same-address atomics serialise chip-wide at ~88 per microsecond)
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) wins += (uint32_t)__shfl_xor((int)wins, off, 64);
@@ -357,37 +409,37 @@ __global__ __launch_bounds__(1024) void k_color_hist(uint64_t max_manifolds, con
 
 // one workgroup: exclusive scan of block_hist in colour-major order (in place) + per-colour totals
 __global__ __launch_bounds__(1024) void k_color_offsets(uint32_t* __restrict__ block_hist, uint32_t nb, StepCounters* __restrict__ ctr) {
+    // every thread owns a run of consecutive entries: sum, one block-wide scan of the 1024 sums, then the run again
+    // (one pass instead of kTotal / 1024 dependent ones: 38 -> ~6 us at 512 workgroups)
     __shared__ uint32_t wtot[16];
     __shared__ uint32_t carry_s;
-    if (threadIdx.x == 0) carry_s = 0;
-    __syncthreads();
     const uint32_t kPerColor = nb;
     const uint32_t kTotal = PHYS_MAX_COLORS * kPerColor;
-    uint32_t ncol = 0;
-    for (uint32_t base = 0; base < kTotal; base += 1024) {
-        const uint32_t idx = base + threadIdx.x;
-        const uint32_t v = idx < kTotal ? block_hist[idx] : 0u;
-        uint32_t inc = v;
-        const int lane = threadIdx.x & 63;
+    const uint32_t per = (kTotal + 1023u) / 1024u;
+    const uint32_t begin = threadIdx.x * per < kTotal ? threadIdx.x * per : kTotal;
+    const uint32_t end = begin + per < kTotal ? begin + per : kTotal;
+    uint32_t sum = 0;
+    for (uint32_t i = begin; i < end; ++i) sum += block_hist[i];
+    uint32_t inc = sum;
+    const int lane = threadIdx.x & 63;
 #pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const uint32_t o = (uint32_t)__shfl_up((int)inc, off, 64);
-            if (lane >= off) inc += o;
-        }
-        if (lane == 63) wtot[threadIdx.x >> 6] = inc;
-        __syncthreads();
-        uint32_t woff = 0;
-        for (uint32_t k = 0; k < (threadIdx.x >> 6); ++k) woff += wtot[k];
-        const uint32_t carry = carry_s;
-        const uint32_t excl = carry + woff + inc - v;
-        if (idx < kTotal) {
-            block_hist[idx] = excl;
-            if (idx % kPerColor == 0) ctr->color_start[idx / kPerColor] = excl;
-        }
-        __syncthreads();
-        if (threadIdx.x == 1023) carry_s = carry + woff + inc;
-        __syncthreads();
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t o = (uint32_t)__shfl_up((int)inc, off, 64);
+        if (lane >= off) inc += o;
     }
+    if (lane == 63) wtot[threadIdx.x >> 6] = inc;
+    __syncthreads();
+    uint32_t running = inc - sum;
+    for (uint32_t k = 0; k < (threadIdx.x >> 6); ++k) running += wtot[k];
+    if (threadIdx.x == 1023) carry_s = running + sum;
+    for (uint32_t i = begin; i < end; ++i) {
+        const uint32_t v = block_hist[i];
+        block_hist[i] = running;
+        if (i % kPerColor == 0) ctr->color_start[i / kPerColor] = running;
+        running += v;
+    }
+    uint32_t ncol = 0;
+    __syncthreads();
     if (threadIdx.x == 0) ctr->color_start[PHYS_MAX_COLORS] = carry_s;
     __syncthreads();
     if (threadIdx.x < PHYS_MAX_COLORS) {
@@ -602,7 +654,7 @@ void launch_narrowphase(phys_world* w) {
                            w->cfg.ground_height, w->max_manifolds, w->man_a.p, w->man_b.p,                             \
                            w->man_color.p, w->man_geo.p, w->man_prio.p, w->color_state.p,                              \
                            w->color_state.p + n, reinterpret_cast<ulonglong2*>(w->ctab.p), cache_mask, stamp,          \
-                           w->counters.p);                                                                             \
+                           w->unc_list.p, w->counters.p);                                                              \
     } while (0)
     if (n <= 200000u) PHYS_NP_LAUNCH(128); else PHYS_NP_LAUNCH(256);
 #undef PHYS_NP_LAUNCH
@@ -614,7 +666,8 @@ static void launch_color_round(phys_world* w, uint32_t round, unsigned blocks) {
     PHYS_PROF(w, PHYS_STAGE_COLOR);
     hipLaunchKernelGGL(k_color_round, dim3(blocks), dim3(kColorThreads), 0, w->stream, round, w->max_manifolds,
                        w->man_a.p, w->man_b.p, w->man_color.p, w->man_prio.p, T[round % 3], T[(round + 1) % 3],
-                       T[(round + 2) % 3], used, w->counters.p);
+                       T[(round + 2) % 3], used, w->unc_list.p + (round & 1u) * w->max_manifolds,
+                       w->unc_list.p + ((round + 1u) & 1u) * w->max_manifolds, w->counters.p);
 }
 
 // Colouring + colour-major renumbering, entirely device-driven: `rounds` round launches (the previous

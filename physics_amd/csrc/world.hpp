@@ -71,6 +71,7 @@ struct StepCounters {
     uint32_t n_ground_manifolds;
     uint32_t flow_ticket;    // k_solve_flow: next (iteration, row chunk) item to hand to a workgroup
     uint32_t n_grid_ovf;     // slot grid: bodies that found their bucket's four slots taken
+    uint32_t unc_count[3];   // colouring rounds: length of the list of uncoloured manifolds read / written / cleared (rotating)
     uint32_t color_count[kMaxColors];  // manifolds per colour
     uint32_t color_start[kMaxColors + 1];
     // LAST member: survives the per-step reset (only the bytes before it are zeroed), so a wave issues the
@@ -214,6 +215,7 @@ struct phys_world {
     phys::DevBuf<float> man_geo;
     phys::DevBuf<uint64_t> man_prio;
     // persistent colouring: two hash tables (this update's / the previous update's), key -> colour
+    phys::DevBuf<uint32_t> unc_list;  // 2 x max_manifolds: ids of the manifolds uncoloured at the start of a round (ping-pong)
     phys::DevBuf<uint64_t> ctab;  // persistent colour table: 2 words per slot {key, stamp << 32 | colour} (kernels.hpp)
     uint32_t ctab_mask = 0;     // capacity - 1 (power of two >= 1.5 * max_manifolds)
     bool ctab_valid = false;    // a table of the previous update exists
