@@ -219,7 +219,8 @@ __device__ __forceinline__ uint32_t color_round_lanes(uint32_t first, uint32_t s
                                                       uint32_t* stage_n = nullptr, uint32_t stage_cap = 0) {
     uint32_t wins = 0;
     for (uint32_t i = first; i < M; i += stride) {
-        const uint32_t m = list ? list[i] : i;
+        // (single-launch loops: a global list was written by other waves of this workgroup one round ago)
+        const uint32_t m = list ? (BYPASS_L1 ? __hip_atomic_load(&list[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : list[i]) : i;
         if (!next_list && man_color[m] != kUncolored) continue;
         const unsigned long long p = man_prio[m];
         const uint32_t a = man_a[m], b = man_b[m];
@@ -339,29 +340,38 @@ __global__ __launch_bounds__(kColorThreads) void k_color_round(uint32_t round, u
     }
 }
 
-// Runs whatever rounds are still needed after the launched ones, inside ONE workgroup (barrier between
-// rounds), so the host never has to ask the device whether the colouring is complete. Normally the
-// first read of n_uncolored is 0 and the kernel ends at once.
+// Runs the rounds that are still needed after the launched ones, inside ONE workgroup (barrier between rounds), over
+// the same shrinking lists, so the host never has to ask the device whether the colouring is complete. Normally
+// nothing or a handful of manifolds is left.
 __global__ __launch_bounds__(kColorThreads) void k_color_finish(uint32_t round, uint64_t max_manifolds,
                                                                const uint32_t* __restrict__ man_a,
                                                                const uint32_t* __restrict__ man_b,
                                                                uint32_t* __restrict__ man_color,
                                                                const uint64_t* __restrict__ man_prio,
                                                                unsigned long long* __restrict__ state /*4n*/, uint64_t n,
+                                                               uint32_t* __restrict__ lists /* 2 x max_manifolds */,
                                                                StepCounters* __restrict__ ctr) {
     __shared__ uint32_t s_left;
+    __shared__ uint32_t s_cnt[2];
     __shared__ uint32_t s_wins[kColorThreads / 64];
-    const uint32_t M = stored_manifolds(ctr, max_manifolds);
-    if (threadIdx.x == 0) s_left = ctr->n_uncolored;
+    if (threadIdx.x == 0) {
+        s_left = ctr->n_uncolored;
+        const uint32_t c = ctr->unc_count[round % 3u];  // what round `round` would have read
+        s_cnt[round & 1u] = (uint64_t)c < max_manifolds ? c : (uint32_t)max_manifolds;
+    }
     __syncthreads();
-    uint32_t left = s_left;
+    const uint32_t left0 = s_left;
+    uint32_t left = left0;
     unsigned long long* used = state;
-    while (left != 0 && left <= M) {
+    while (left != 0) {
         unsigned long long* top = state + (1 + round % 3) * n;
         unsigned long long* top_next = state + (1 + (round + 1) % 3) * n;
         unsigned long long* top_clr = state + (1 + (round + 2) % 3) * n;
-        uint32_t wins = color_round_lanes<true>(threadIdx.x, kColorThreads, M, nullptr, nullptr, nullptr, man_a, man_b, man_color, man_prio, top,
-                                                top_next, top_clr, used, ctr);
+        const uint32_t cur = round & 1u, nxt = cur ^ 1u;
+        if (threadIdx.x == 0) s_cnt[nxt] = 0;
+        __syncthreads();
+        uint32_t wins = color_round_lanes<true>(threadIdx.x, kColorThreads, s_cnt[cur], lists + cur * max_manifolds, lists + nxt * max_manifolds,
+                                                &s_cnt[nxt], man_a, man_b, man_color, man_prio, top, top_next, top_clr, used, ctr);
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) wins += (uint32_t)__shfl_xor((int)wins, off, 64);
         if ((threadIdx.x & 63) == 0) s_wins[threadIdx.x >> 6] = wins;
@@ -374,7 +384,7 @@ __global__ __launch_bounds__(kColorThreads) void k_color_finish(uint32_t round, 
         __syncthreads();
         if (t == 0) break;  // cannot happen (the highest priority always wins); never spin
     }
-    if (threadIdx.x == 0 && left != s_left) {
+    if (threadIdx.x == 0 && left != left0) {
         ctr->n_uncolored = left;
         ctr->color_rounds = round;
     }
@@ -718,7 +728,10 @@ void launch_coloring(phys_world* w) {
     } else {
     if (known) {
         const uint32_t base = full ? w->hint.full_rounds : w->hint.color_rounds;
-        rounds = base + 2 + base / 4;  // surplus launches exit at once; k_color_finish covers a miss
+        // as many launches as the last update of this kind needed; k_color_finish runs what is still missing over the
+        // same lists (measured: handing it the second half of the rounds - one workgroup, ~10 us per round with a few
+        // thousand manifolds left - is slower than the launches it saves, and far slower on a full re-colouring)
+        rounds = base;
         for (uint32_t r = 0; r < rounds; ++r) launch_color_round(w, r, blocks);
     } else {
         // first step after phys_set_bodies: nothing is known about the scene yet, so this one step asks the
@@ -731,7 +744,7 @@ void launch_coloring(phys_world* w) {
             if (w->h_counters->n_uncolored == 0 || w->h_counters->overflow) break;
         }
     }
-    { PHYS_PROF(w, PHYS_STAGE_COLOR); hipLaunchKernelGGL(k_color_finish, dim3(1), dim3(kColorThreads), 0, s, rounds, w->max_manifolds, w->man_a.p, w->man_b.p, w->man_color.p, w->man_prio.p, w->color_state.p, (uint64_t)n, w->counters.p); }
+    { PHYS_PROF(w, PHYS_STAGE_COLOR); hipLaunchKernelGGL(k_color_finish, dim3(1), dim3(kColorThreads), 0, s, rounds, w->max_manifolds, w->man_a.p, w->man_b.p, w->man_color.p, w->man_prio.p, w->color_state.p, (uint64_t)n, w->unc_list.p, w->counters.p); }
     // workgroups of the colour sort: sized from the hint (any value is correct: the kernels stride)
     uint32_t nb = kSortBlocksMax;
     if (w->hint.valid) {
