@@ -53,8 +53,9 @@ KERNEL_OF_STAGE = {
 DEFAULT_PREROLL = {"c1": 100, "c2": 150, "c3": 150, "c5": 30, "t1m": 100, "c4": 0}
 
 
-def stage_bytes(stage, st, iters):
-    """Algorithmic HBM bytes of one STEP spent in `stage` (formulas: DESIGN.md 'algorithmic bytes')."""
+def stage_bytes(stage, st, iters, cluster=False):
+    """Algorithmic HBM bytes of one STEP spent in `stage` (formulas: DESIGN.md 'algorithmic bytes').
+    cluster: the step ran the cluster solver, whose rows are compact and built without reading the bodies."""
     n, p, m, k = st["n_bodies"], st["n_pairs"], st["n_manifolds"], st["n_contacts"]
     mb = m - st["n_ground_manifolds"]
     if stage == "step_full":
@@ -71,9 +72,17 @@ def stage_bytes(stage, st, iters):
         return 96 * p + 44 * st["n_ground_manifolds"] + 100 * m
     if stage == "color":
         return 28 * m  # ids + priority + colour + slot, once
+    if stage == "rows" and cluster:
+        # manifold record read (ids, count, normal 24 + 16 per point), compact row written (32 + 16 per point),
+        # permutation + colour 8, per body side {used mask 8, cluster slot 4, remote-colour mask 8}
+        return (24 + 32 + 8) * m + 32 * k + 20 * (m + mb)
     if stage == "rows":
         return 100 * m + 24 * m + 76 * k + 52 * (m + mb)
-    if stage in ("solve", "solve_flow", "solve_cluster"):
+    if stage == "solve_cluster":
+        # compact rows streamed once per iteration: header + normal 32 per manifold; per point {contact point, bias} 16,
+        # accumulated impulses 12 read + 12 written, row masses 12 read (written once); body velocities stay in LDS
+        return iters * (32 * m + 52 * k)
+    if stage in ("solve", "solve_flow"):
         # (k_solve_flow makes all iterations in one launch; same job, same compulsory bytes)
         # per body and iteration: v, w read 24 + written 24, inverse mass 4, inverse inertia diagonal 12
         # (all benchmark scenes have diagonal tensors; 36 with a full tensor)
@@ -213,6 +222,31 @@ def timed_repetition(rig, preroll, warmup, steps, want_state=False):
     return elapsed, st, cross, state
 
 
+def timed_period(rig, preroll, warmup):
+    """One more fresh world: from the start of the timed window, PHYS_COLOR_CACHE_PERIOD (64) consecutive steps - exactly
+    one of them is the periodic full re-colouring update (contact_solve.h), which a 20-step window may or may not
+    contain. Returns steps per second over the whole period, and the slowest single step in ms."""
+    import torch
+    w = rig.make_world()
+    rig.advance(w, preroll)
+    rig.advance(w, warmup)
+    rig.fence(w)
+    period = 64
+    slowest = 0.0
+    t0 = time.perf_counter()
+    for _ in range(period):
+        t1 = time.perf_counter()
+        rig.advance(w, 1)
+        w.sync()
+        slowest = max(slowest, time.perf_counter() - t1)
+    torch.cuda.synchronize()
+    if rig.dist is not None:
+        rig.dist.barrier()
+    elapsed = rig.max_over_ranks(time.perf_counter() - t0)
+    w.close()
+    return period / elapsed, 1e3 * slowest
+
+
 def profile_window(rig, preroll, warmup, steps, workload_key):
     """The SAME window once more on a fresh world, every launch bracketed by HIP events on the library's stream.
     Returns the roofline object of the dominant kernel, the per-stage table and the scene stats after the window."""
@@ -237,7 +271,8 @@ def profile_window(rig, preroll, warmup, steps, workload_key):
     if not kernel_stages:
         return None, table, st
     dom = max(kernel_stages, key=lambda s: table[s]["ms_per_step"])
-    b_step = stage_bytes(dom, st, iters)
+    cluster = "solve_cluster" in table
+    b_step = stage_bytes(dom, st, iters, cluster)
     if dom == "solve" and "solve_tail" in table:
         # k_solve_color only runs the colours that got a launch of their own; the trailing small colours
         # (<= 512 manifolds each, at least two of them) are solved by k_solve_tail. Scale the stage's bytes by the
@@ -253,7 +288,7 @@ def profile_window(rig, preroll, warmup, steps, workload_key):
     per_launch = b_step / max(launches, 1e-9)
     dur_s = table[dom]["avg_launch_us"] * 1e-6
     achieved = per_launch / dur_s / 1e9 if dur_s > 0 else 0.0
-    total_bytes = sum(stage_bytes(s, st, iters) for s in kernel_stages)
+    total_bytes = sum(stage_bytes(s, st, iters, cluster) for s in kernel_stages)
     family = KERNEL_OF_STAGE[dom]
     window = {"preroll": preroll, "warmup": warmup, "steps": steps}
     prof_name, prof_us, traffic, note = committed_profile_fields(workload_key, family, window, st)
@@ -352,6 +387,12 @@ def measure_workload(rig, args, preroll, reps, with_cpu):
         "pairs_per_sec": round(pairs_total * args.steps / med, 1),
         "scene_stats": st, "n_bodies": n_total, "preroll": preroll,
     }
+    if (rig.scene.flags & 1) and not (rig.scene.flags & 8) and st["n_manifolds"] > 0:  # FLAG_COLLISIONS, not broad-phase-only
+        sps, slowest = timed_period(rig, preroll, args.warmup)
+        rec["full_period"] = {"steps": 64, "steps_per_sec": round(sps, 2), "slowest_step_ms": round(slowest, 3),
+                              "note": "64 consecutive steps from the start of the timed window, synchronised after every step: "
+                                      "contains exactly one full re-colouring update (every 64th update, contact_solve.h), which the "
+                                      "timed window may not; the scene keeps evolving over the period (a growing pile gets slower)"}
     # sharded: every rank steps through the profile window (the exchange is a collective); rank 0 reports its slab
     roof, table = None, {}
     if rig.rank == 0 or rig.sharded:
@@ -484,6 +525,8 @@ def main():
             out["stages"] = rec["stages"]
         if "cpu_baseline" in rec:
             out["cpu_baseline"] = rec["cpu_baseline"]
+        if "full_period" in rec:
+            out["full_period"] = rec["full_period"]
 
     if rank == 0 and not sharded and not args.no_extra and args.workload == "c5":
         # the other single-GPU configurations, measured the same way (fewer repetitions: they are sub-records)

@@ -24,6 +24,12 @@ for k in range(count):
     w.update(scenes.DT_NANOS)
     w.sync()
     out.append((time.perf_counter() - t0) * 1e3)
+if len(sys.argv) > 4:  # stage times of ONE update: python tools/step_times.py c5 64 0 stages  -> update number 64
+    w.profile_enable(True)
+    w.update(scenes.DT_NANOS)
+    w.sync()
+    prof, psteps = w.profile_get()
+    print("stages of update", first + count, {k: (round(ms, 3), n) for k, (ms, n) in prof.items() if n})
 st = w.get_stats()
 print(wl, "steps", first, "..", first + count, "manifolds", st.n_manifolds, "colours", st.n_colors, "rounds", st.color_rounds)
 print(" ".join(f"{t:.2f}" for t in out))
