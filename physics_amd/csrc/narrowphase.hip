@@ -29,7 +29,7 @@ __device__ __forceinline__ geom_t load_geom(uint32_t i, const float* __restrict_
 }
 
 // kNpThreads: 128 for small scenes (latency-bound: more workgroups in flight, the LDS slice of the clipper
-// halves), 256 for large ones (throughput-bound: fewer, fuller workgroups)
+// halves), 256 for everything else (launch_narrowphase)
 template <int kNpThreads>
 __global__ __launch_bounds__(kNpThreads) void k_narrowphase(
     uint32_t n_ground /* bodies tested against the plane (0 = no ground) */, uint32_t n_owned /* bodies at or beyond this
@@ -666,7 +666,11 @@ void launch_narrowphase(phys_world* w) {
                            w->color_state.p + n, reinterpret_cast<ulonglong2*>(w->ctab.p), cache_mask, stamp,          \
                            w->unc_list.p, w->counters.p);                                                              \
     } while (0)
-    if (n <= 200000u) PHYS_NP_LAUNCH(128); else PHYS_NP_LAUNCH(256);
+    static const int np_threads_env = getenv("PHYS_DEBUG_NP_THREADS") ? atoi(getenv("PHYS_DEBUG_NP_THREADS")) : 0;  // measurements
+    // 128 threads only while the whole stage is a few workgroups (C2: 10k manifolds); measured at 230k manifolds (C3):
+    // 0.175 ms with 128 threads, 0.133 with 256; at 2.9M (C5): 0.86 vs 0.55, and 512 no better than 256
+    const bool few = w->hint.valid ? w->hint.n_manifolds <= 32768u : n <= 200000u;
+    if (np_threads_env ? np_threads_env == 128 : few) PHYS_NP_LAUNCH(128); else PHYS_NP_LAUNCH(256);
 #undef PHYS_NP_LAUNCH
 }
 

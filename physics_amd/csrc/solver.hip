@@ -395,11 +395,24 @@ constexpr long long kFlowTimeoutTicks = 300000000ll;  // 3 s of the 100 MHz wall
 constexpr uint64_t kFlowMaxManifolds = 400000;        // above: one launch per colour streams better
 constexpr uint64_t kFlowQuadMaxManifolds = 64000;     // below: four lanes per manifold (k_solve_flow_quad); 45k: +13 %, 108k: -32 %
 
+// Work items are SOFTWARE-PIPELINED inside a workgroup: while item k waits for its bodies and is solved, the rows of
+// item k + 1 (its ticket is taken one item ahead) are already on their way, and so are - issued once those rows have
+// arrived, i.e. behind the Jacobians of item k - the records of its bodies. At one wave per SIMD nobody else hides
+// these two dependent round trips (~4.5 us of the ~14 us an item cost on the 1M-cube scene: 11.5k items over 256
+// workgroups). A workgroup still finishes its items in ticket order, so the earliest unfinished item of the solve is
+// always somebody's CURRENT item: the no-deadlock argument above holds. `pipeline` = 0 takes the next item only when
+// the current one is done: holding an item ahead means it cannot go to whichever workgroup is free first, and where a
+// colour class is much smaller than the launch (C3: 64 items per colour, 256 workgroups) the solve is bound by the
+// chain of hand-offs, not by item throughput - there the look-ahead costs 10 % instead of saving it (launch_solver).
+struct FlowRowRaw { uint4 h; float4 nn, t01, t23, p[8]; };
+struct FlowBodies { m33 IA, IB; float ima, imb, massA, massB; v3 vA, wA, vB, wB; };
+
 template <bool DIAG>
 __global__ __launch_bounds__(256) void k_solve_flow(StepCounters* __restrict__ ctr, uint32_t iterations, uint32_t epoch,
                                                     RowArrays rows, float friction,
                                                     const float* __restrict__ inv_inertia, uint32_t inertia_stride,
-                                                    float* vel, float* flow_vel, uint32_t n_bodies, long long timeout_ticks) {
+                                                    float* vel, float* flow_vel, uint32_t n_bodies, long long timeout_ticks,
+                                                    uint32_t pipeline) {
     __shared__ uint32_t s_item;
     if (ctr->overflow) return;
     const uint32_t M = ctr->n_manifolds;
@@ -410,48 +423,110 @@ __global__ __launch_bounds__(256) void k_solve_flow(StepCounters* __restrict__ c
     const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(rows.acc, 0, cap * 64u, 0x00020000);
     const uint32_t etag = epoch << 16;
     const long long t_start = wall_clock64();
-    for (;;) {
+    auto take = [&]() -> uint32_t {  // next work item in solve order (block-uniform)
         __syncthreads();
         if (threadIdx.x == 0)
             s_item = (__hip_atomic_load(&ctr->overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 16u)
                          ? 0xFFFFFFFFu : atomicAdd(&ctr->flow_ticket, 1u);
         __syncthreads();
-        const uint32_t L = s_item;
-        if (L >= total) return;
-        const uint32_t it = L / nchunks, chunk = L - it * nchunks;
+        return s_item;
+    };
+    auto row_of = [&](uint32_t L) -> uint32_t {  // this lane's row of item L (>= M: none)
+        if (L >= total) return 0xFFFFFFFFu;
+        const uint32_t it = L / nchunks;
+        return (L - it * nchunks) * blockDim.x + threadIdx.x;
+    };
+    auto fetch_row = [&](uint32_t d, FlowRowRaw& r) {
+        // every plane at once, whatever the point count turns out to be: ONE round trip
+        r.h = rows.hdr[d];
+        r.nn = rows.n[d];
+        r.t01 = rows.tb[d];
+        r.t23 = rows.tb[cap + d];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) r.p[k] = rows.pt[(size_t)k * cap + d];
+    };
+    auto fetch_bodies = [&](const FlowRowRaw& r, FlowBodies& g) {
+        // everything of the two bodies that is constant during the solve; v, w are the body's state only for ticket 0
+        g.IA = ld_inertia<DIAG>(inv_inertia, r.h.x * inertia_stride);
+        const BodyVel A0 = ld_vel(vel, r.h.x);
+        g.ima = A0.inv_mass; g.massA = A0.mass; g.vA = A0.v; g.wA = A0.w;
+        if (r.h.y != PHYS_GROUND_ID) {
+            g.IB = ld_inertia<DIAG>(inv_inertia, r.h.y * inertia_stride);
+            const BodyVel B0 = ld_vel(vel, r.h.y);
+            g.imb = B0.inv_mass; g.massB = B0.mass; g.vB = B0.v; g.wB = B0.w;
+        }
+    };
+    auto clear_bodies = [&](FlowBodies& g) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) { g.IA.m[k] = 0.0f; g.IB.m[k] = 0.0f; }
+        g.ima = 0.0f; g.imb = 0.0f; g.massA = 0.0f; g.massB = 0.0f;
+        g.vA = v3_make(0.0f, 0.0f, 0.0f); g.wA = g.vA; g.vB = g.vA; g.wB = g.vA;
+    };
+    auto clear_row = [&](FlowRowRaw& r) {
+        r.h = make_uint4(0u, PHYS_GROUND_ID, 0u, 0u);
+        r.nn = make_float4(0.0f, 0.0f, 0.0f, 0.0f); r.t01 = r.nn; r.t23 = r.nn;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) r.p[k] = r.nn;
+    };
+    // prologue: the first item with its rows and bodies
+    uint32_t L = take();
+    FlowRowRaw raw, raw_next;
+    FlowBodies bod, bod_next;
+    clear_row(raw); clear_bodies(bod);
+    {
+        const uint32_t d0 = row_of(L);
+        if (d0 < M) { fetch_row(d0, raw); fetch_bodies(raw, bod); }
+    }
+    while (L < total) {
+        uint32_t L_next = 0xFFFFFFFFu, d_next = 0xFFFFFFFFu;
+        clear_row(raw_next); clear_bodies(bod_next);
+        if (pipeline) {
+            L_next = take();
+            d_next = row_of(L_next);
+            if (d_next < M) fetch_row(d_next, raw_next);
+        }
+        // ---- item L: unpack the row (same values as load_row)
+        const uint32_t it = L / nchunks;
         const bool last_it = it + 1 == iterations;
-        const uint32_t d = chunk * blockDim.x + threadIdx.x;
+        const uint32_t d = (L - it * nchunks) * blockDim.x + threadIdx.x;
         bool done = d >= M;
         RowRegs R;
-        uint32_t tA = 0, tB = 0;
-        bool finalA = false, finalB = false;
-        m33 IA, IB;
-        float ima = 0.0f, imb = 0.0f, massA = 0.0f, massB = 0.0f;
-        v3 vA = v3_make(0.0f, 0.0f, 0.0f), wA = vA, vB = vA, wB = vA;
+        R.a = raw.h.x; R.b = raw.h.y; R.ticket = raw.h.w;
+        {
+            solver_manifold_t& sm = R.sm;
+            sm.count = done ? 0 : (int)raw.h.z;
+            sm.has_b = !done && R.b != PHYS_GROUND_ID;
+            sm.n = v3_make(raw.nn.x, raw.nn.y, raw.nn.z);
+            if (done) sm.n = v3_make(0.0f, 1.0f, 0.0f);
+            tangent_basis(sm.n, &sm.t1, &sm.t2);
 #pragma unroll
-        for (int k = 0; k < 9; ++k) { IA.m[k] = 0.0f; IB.m[k] = 0.0f; }
-        R.a = 0; R.b = PHYS_GROUND_ID; R.sm.count = 0; R.sm.has_b = 0;
-        if (!done) {
-            // everything that is constant during the solve: plain loads, in flight while the row waits
-            load_row<false>(R, d, rows);
-            const uint32_t rankA = R.ticket & 0xFFu, degA = (R.ticket >> 8) & 0xFFu;
-            const uint32_t rankB = (R.ticket >> 16) & 0xFFu, degB = R.ticket >> 24;
-            tA = it * degA + rankA;
-            finalA = last_it && rankA + 1 == degA;
-            IA = ld_inertia<DIAG>(inv_inertia, R.a * inertia_stride);
-            const BodyVel A0 = ld_vel(vel, R.a);  // v, w are the body's state only for ticket 0; the masses always
-            ima = A0.inv_mass; massA = A0.mass; vA = A0.v; wA = A0.w;
-            if (R.sm.has_b) {
-                tB = it * degB + rankB;
-                finalB = last_it && rankB + 1 == degB;
-                IB = ld_inertia<DIAG>(inv_inertia, R.b * inertia_stride);
-                const BodyVel B0 = ld_vel(vel, R.b);
-                imb = B0.inv_mass; massB = B0.mass; vB = B0.v; wB = B0.w;
+            for (int k = 0; k < 4; ++k) {
+                contact_row_t& c = sm.row[k];
+                c.rA = v3_make(0.0f, 0.0f, 0.0f); c.rB = c.rA;
+                c.normal_mass = 0.0f; c.tangent_mass[0] = 0.0f; c.tangent_mass[1] = 0.0f; c.bias = 0.0f;
+                c.pn = 0.0f; c.pt[0] = 0.0f; c.pt[1] = 0.0f;
+                if (k < sm.count) {
+                    const float4 p0 = raw.p[2 * k], p1 = raw.p[2 * k + 1];
+                    c.rA = v3_make(p0.x, p0.y, p0.z); c.normal_mass = p0.w;
+                    c.rB = v3_make(p1.x, p1.y, p1.z); c.tangent_mass[0] = p1.w;
+                    const float4 t = k < 2 ? raw.t01 : raw.t23;
+                    c.tangent_mass[1] = (k & 1) ? t.z : t.x;
+                    c.bias = (k & 1) ? t.w : t.y;
+                }
             }
         }
+        const uint32_t rankA = R.ticket & 0xFFu, degA = (R.ticket >> 8) & 0xFFu;
+        const uint32_t rankB = (R.ticket >> 16) & 0xFFu, degB = R.ticket >> 24;
+        const uint32_t tA = done ? 0u : it * degA + rankA, tB = (done || !R.sm.has_b) ? 0u : it * degB + rankB;
+        const bool finalA = !done && last_it && rankA + 1 == degA, finalB = !done && R.sm.has_b && last_it && rankB + 1 == degB;
+        const m33 IA = bod.IA, IB = bod.IB;
+        const float ima = bod.ima, imb = bod.imb, massA = bod.massA, massB = bod.massB;
+        v3 vA = bod.vA, wA = bod.wA, vB = bod.vB, wB = bod.wB;
         // the velocity-independent part of every row, while the row waits: the chain behind the wait is short
         solver_jac_t J;
         solver_jacobians(&R.sm, ima, &IA, imb, &IB, &J);
+        // the rows of the next item have arrived by now (they were asked for before all of the above): its bodies
+        if (pipeline && d_next < M) fetch_bodies(raw_next, bod_next);
         // what is still missing (a matched granule cannot change any more: this row is its next writer)
         bool needA = !done && tA != 0, needB = !done && R.sm.has_b && tB != 0, needAcc = !done && it != 0;
         uint32_t sweeps = 0;
@@ -530,6 +605,14 @@ __global__ __launch_bounds__(256) void k_solve_flow(StepCounters* __restrict__ c
                 }
             }
         }
+        if (!pipeline) {
+            L_next = take();
+            d_next = row_of(L_next);
+            if (d_next < M) { fetch_row(d_next, raw_next); fetch_bodies(raw_next, bod_next); }
+        }
+        L = L_next;
+        raw = raw_next;
+        bod = bod_next;
     }
 }
 
@@ -990,11 +1073,17 @@ void launch_solver(phys_world* w, float dt) {
         const uint64_t most = quad ? 224 : 256;
         if (items > most) items = most;  // the remaining items are taken by the same workgroups
         PHYS_PROF(w, PHYS_STAGE_SOLVE_FLOW);
-#define PHYS_FLOW_LAUNCH(K, D) hipLaunchKernelGGL((K<D>), dim3((unsigned)items), dim3(threads), 0, s, w->counters.p, w->cfg.solver_iterations, \
-                               w->flow_epoch, rows, sp.friction, inertia, stride, w->vel.p, w->flow_vel.p, (uint32_t)w->n, timeout_ticks)
-        if (quad) { if (diag) PHYS_FLOW_LAUNCH(k_solve_flow_quad, true); else PHYS_FLOW_LAUNCH(k_solve_flow_quad, false); }
-        else { if (diag) PHYS_FLOW_LAUNCH(k_solve_flow, true); else PHYS_FLOW_LAUNCH(k_solve_flow, false); }
-#undef PHYS_FLOW_LAUNCH
+        // look one work item ahead (k_solve_flow) while a colour class keeps a good part of the launch busy; below that the
+        // solve is a chain of hand-offs and an item held ahead only waits (C3: 16k rows per colour, 65k lanes: +10 %;
+        // 1M cubes: 41k rows per colour: -10 %). PHYS_DEBUG_FLOW_PIPELINE=0/1 forces it (measurements; same bits).
+        static const char* pipe_env = getenv("PHYS_DEBUG_FLOW_PIPELINE");
+        const uint64_t per_color = m_hint / (h.valid && h.n_colors ? h.n_colors : 1u);
+        const uint32_t pipeline = pipe_env ? (uint32_t)(pipe_env[0] == '1') : (uint32_t)(4 * per_color >= threads * items);
+#define PHYS_FLOW_ARGS dim3((unsigned)items), dim3(threads), 0, s, w->counters.p, w->cfg.solver_iterations, \
+                       w->flow_epoch, rows, sp.friction, inertia, stride, w->vel.p, w->flow_vel.p, (uint32_t)w->n, timeout_ticks
+        if (quad) { if (diag) hipLaunchKernelGGL(k_solve_flow_quad<true>, PHYS_FLOW_ARGS); else hipLaunchKernelGGL(k_solve_flow_quad<false>, PHYS_FLOW_ARGS); }
+        else { if (diag) hipLaunchKernelGGL(k_solve_flow<true>, PHYS_FLOW_ARGS, pipeline); else hipLaunchKernelGGL(k_solve_flow<false>, PHYS_FLOW_ARGS, pipeline); }
+#undef PHYS_FLOW_ARGS
         return;
     }
     // colours [0, big) get a launch each; [big, n_colours) go through the single-workgroup tail

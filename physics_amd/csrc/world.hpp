@@ -17,7 +17,7 @@ namespace phys {
 
 constexpr int kMaxColors = 64;  // == PHYS_MAX_COLORS of include/spec/contact_solve.h
 constexpr uint64_t kClusterMinBodies = 32768;  // below: the dataflow kernels win anyway (few launches' worth of rows)
-constexpr uint64_t kClusterMinManifolds = 300000;  // fewer rows: the single-launch dataflow kernel (measured crossover)
+constexpr uint64_t kClusterMinManifolds = 200000;  // measured: C3 (230k manifolds, 15 colours) 0.61 ms against 0.66 with k_solve_flow
 constexpr uint32_t kClusterMaxSlots = 2496;    // bodies per cluster whose {v, w, x, I^-1} fit one CU's LDS (64 B each: 156 KiB; 13-bit slot field)
 
 void set_error(const std::string& msg);

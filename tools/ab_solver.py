@@ -32,6 +32,10 @@ VARIANTS = {
     "cl_remass": {"PHYS_DEBUG_ABLATE": "32"},   # same bits: row masses remade in every iteration
     "cl_norot_remass": {"PHYS_DEBUG_ABLATE": "48"},
     "cluster2": {"PHYS_DEBUG_CLUSTERS_PER_CU": "2"},
+    "flow_pipe": {"PHYS_DEBUG_FLOW_MAX": "100000000", "PHYS_DEBUG_NO_CLUSTER": "1", "PHYS_DEBUG_FLOW_PIPELINE": "1"},
+    "flow_nopipe": {"PHYS_DEBUG_FLOW_MAX": "100000000", "PHYS_DEBUG_NO_CLUSTER": "1", "PHYS_DEBUG_FLOW_PIPELINE": "0"},
+    "np128": {"PHYS_DEBUG_NP_THREADS": "128"},
+    "np256": {"PHYS_DEBUG_NP_THREADS": "256"},
     "no_ctab": {"PHYS_DEBUG_NO_CTAB": "1"},   # timing of the rows stage without the colour-table build (colours differ)
     "cl_allcus": {"PHYS_DEBUG_CLUSTER_SPARE": "0"},
     "cl_spare16": {"PHYS_DEBUG_CLUSTER_SPARE": "16"},
