@@ -250,6 +250,9 @@ int32_t phys_get_cross_pairs(phys_world* w, uint32_t* pairs_out /*2*cap*/, uint6
 #define PHYS_HALO_BODY_RECORD_BYTES 96u
 int32_t phys_set_slab(phys_world* w, float x_lo, float x_hi, float reach);
 int32_t phys_halo_pack_bodies(phys_world* w, void* dev_records_out, uint64_t cap);
+/* the bodies within reach of ONE slab face only: face < 0 the low face (what rank r - 1 may need), face > 0 the high
+ * face (rank r + 1), 0 both (= phys_halo_pack_bodies). What a neighbour exchange sends (phys_comm_set_neighbours). */
+int32_t phys_halo_pack_bodies_face(phys_world* w, void* dev_records_out, uint64_t cap, int32_t face);
 int32_t phys_halo_unpack_ghosts(phys_world* w, const void* dev_records, uint64_t n_records, uint64_t skip_first,
                                 uint64_t skip_count);
 int32_t phys_get_global_ids(phys_world* w, uint32_t* out /* n_bodies + max_ghosts */);
@@ -269,6 +272,11 @@ int32_t phys_comm_create(phys_world* w, const uint8_t id[PHYS_COMM_ID_BYTES], in
                          phys_comm** out);
 int32_t phys_comm_create_local(phys_world** worlds, int32_t n, uint64_t capacity, phys_comm** comms_out /*n*/);
 int32_t phys_comm_destroy(phys_comm* c);
+/* enable != 0: the ranks are x-slabs ORDERED BY RANK and none is thinner than the reach, so only ranks r - 1 and r + 1 can
+ * hold bodies near this rank's faces: the exchange becomes one grouped ncclSend / ncclRecv pair per neighbour (direct xGMI
+ * links, two blocks to scan) instead of an all-gather of every rank's block. Every rank of the communicator must choose
+ * the same. Default: all-gather (right for any partition). */
+int32_t phys_comm_set_neighbours(phys_comm* c, int32_t enable);
 int32_t phys_halo_exchange(phys_world* w, phys_comm* c);
 /* the n collectives of a step as ONE group: required when one thread drives the comms of phys_comm_create_local */
 int32_t phys_halo_exchange_all(phys_world** worlds, phys_comm** comms, int32_t n);

@@ -161,12 +161,14 @@ PROTOTYPES = {
     "phys_get_cross_pairs": (C.c_int32, [C.c_void_p, u32p, C.c_uint64, u64p]),
     "phys_set_slab": (C.c_int32, [C.c_void_p, C.c_float, C.c_float, C.c_float]),
     "phys_halo_pack_bodies": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64]),
+    "phys_halo_pack_bodies_face": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32]),
     "phys_halo_unpack_ghosts": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64]),
     "phys_get_global_ids": (C.c_int32, [C.c_void_p, u32p]),
     "phys_comm_unique_id": (C.c_int32, [C.POINTER(C.c_uint8)]),
     "phys_comm_create": (C.c_int32, [C.c_void_p, C.POINTER(C.c_uint8), C.c_int32, C.c_int32, C.c_uint64, C.POINTER(C.c_void_p)]),
     "phys_comm_create_local": (C.c_int32, [C.POINTER(C.c_void_p), C.c_int32, C.c_uint64, C.POINTER(C.c_void_p)]),
     "phys_comm_destroy": (C.c_int32, [C.c_void_p]),
+    "phys_comm_set_neighbours": (C.c_int32, [C.c_void_p, C.c_int32]),
     "phys_halo_exchange": (C.c_int32, [C.c_void_p, C.c_void_p]),
     "phys_halo_exchange_all": (C.c_int32, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int32]),
     "phys_slab_histogram": (C.c_int32, [f32p, C.c_uint64, C.c_float, C.c_float, C.c_uint32, u64p]),

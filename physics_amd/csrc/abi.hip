@@ -639,6 +639,11 @@ int32_t phys_halo_pack_bodies(phys_world* w, void* dev_records_out, uint64_t cap
     ENTER(w);
     return halo_pack_bodies(w, dev_records_out, cap);
 }
+int32_t phys_halo_pack_bodies_face(phys_world* w, void* dev_records_out, uint64_t cap, int32_t face) {
+    ENTER(w);
+    const float far = 3.0e38f;
+    return halo_pack_bodies_faces(w, dev_records_out, cap, face > 0 ? -far : w->slab_lo, face < 0 ? far : w->slab_hi);
+}
 int32_t phys_halo_unpack_ghosts(phys_world* w, const void* dev_records, uint64_t n_records, uint64_t skip_first,
                                 uint64_t skip_count) {
     ENTER(w);

@@ -6,9 +6,13 @@
 // must be the one built against the HIP runtime of the process. Search order: $PHYS_RCCL_PATH, "librccl.so.1" (the
 // loader finds an already mapped copy by its SONAME first), /opt/rocm/lib/librccl.so.1.
 // One communicator rank per world = per GPU; every collective is enqueued on the world's own stream between its
-// pack and unpack kernels, so a step's exchange needs no host synchronisation. xGMI is point to point and the
-// message is small (C5 slab face: ~16k boundary bodies x 96 B = 1.5 MB per rank, C2: ~100 KB), i.e. latency-bound:
-// ONE all-gather of fixed-size blocks per step, no count exchange, no ragged second collective.
+// pack and unpack kernels, so a step's exchange needs no host synchronisation. Fixed-size blocks, no count exchange,
+// no ragged second collective. Two topologies:
+//   all-gather (default)  every rank receives every rank's block: right for any partition, but n - 1 blocks travel to
+//                         each rank and every rank scans n blocks (8 ranks of C5: 7 x 6 MB per rank and step);
+//   neighbours            phys_comm_set_neighbours: ranks are slabs ordered along x by rank, none thinner than the reach,
+//                         so only ranks r - 1 and r + 1 can hold bodies near this rank's faces: one grouped
+//                         ncclSend / ncclRecv pair per neighbour over the direct xGMI link, two blocks to scan.
 #include <dlfcn.h>
 
 #include <algorithm>
@@ -37,6 +41,8 @@ struct RcclApi {
     int (*CommInitAll)(nccl_comm_t*, int, const int*) = nullptr;
     int (*CommDestroy)(nccl_comm_t) = nullptr;
     int (*AllGather)(const void*, void*, size_t, int, nccl_comm_t, hipStream_t) = nullptr;
+    int (*Send)(const void*, size_t, int, int, nccl_comm_t, hipStream_t) = nullptr;
+    int (*Recv)(void*, size_t, int, int, nccl_comm_t, hipStream_t) = nullptr;
     int (*GroupStart)() = nullptr;
     int (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
@@ -65,11 +71,13 @@ RcclApi& rccl() {
         PHYS_RCCL_SYM(CommInitAll, "ncclCommInitAll");
         PHYS_RCCL_SYM(CommDestroy, "ncclCommDestroy");
         PHYS_RCCL_SYM(AllGather, "ncclAllGather");
+        PHYS_RCCL_SYM(Send, "ncclSend");
+        PHYS_RCCL_SYM(Recv, "ncclRecv");
         PHYS_RCCL_SYM(GroupStart, "ncclGroupStart");
         PHYS_RCCL_SYM(GroupEnd, "ncclGroupEnd");
         PHYS_RCCL_SYM(GetErrorString, "ncclGetErrorString");
 #undef PHYS_RCCL_SYM
-        if (!api.error.empty() && api.GetUniqueId && api.CommInitRank && api.CommInitAll && api.CommDestroy && api.AllGather &&
+        if (!api.error.empty() && api.GetUniqueId && api.CommInitRank && api.CommInitAll && api.CommDestroy && api.AllGather && api.Send && api.Recv &&
             api.GroupStart && api.GroupEnd && api.GetErrorString)
             api.error.clear();  // an earlier candidate failed to load, a later one is complete
     });
@@ -78,7 +86,7 @@ RcclApi& rccl() {
 
 int32_t rccl_ready() {
     RcclApi& api = rccl();
-    if (!api.handle || !api.AllGather) {
+    if (!api.handle || !api.AllGather || !api.Send || !api.Recv || !api.GroupStart || !api.GroupEnd) {
         set_error("RCCL is not available (librccl.so.1): " + api.error);
         return PHYS_ERR_UNSUPPORTED;
     }
@@ -98,28 +106,64 @@ struct phys_comm {
     int32_t rank = 0, n_ranks = 1;
     int device = 0;
     uint64_t cap = 0;        // records per rank and step
-    void* send = nullptr;    // cap records of PHYS_HALO_BODY_RECORD_BYTES (the 32-byte AABB records use the front of it)
-    void* recv = nullptr;    // n_ranks x cap records
+    void* send = nullptr;    // 2 x cap records of PHYS_HALO_BODY_RECORD_BYTES (the 32-byte AABB records use the front of a block);
+                             // all-gather: block 0 only; neighbours: block 0 for rank - 1 (low face), block 1 for rank + 1
+    void* recv = nullptr;    // max(n_ranks, 2) x cap records
+    bool neighbours = false; // block 0 of recv: from rank - 1, block 1: from rank + 1 (all 0xFF where there is none)
 };
 
 static int32_t comm_buffers(phys_comm* c) {
     PHYS_HIP_TRY(hipSetDevice(c->device));
-    PHYS_HIP_TRY(hipMalloc(&c->send, c->cap * PHYS_HALO_BODY_RECORD_BYTES));
-    PHYS_HIP_TRY(hipMalloc(&c->recv, (size_t)c->n_ranks * c->cap * PHYS_HALO_BODY_RECORD_BYTES));
+    PHYS_HIP_TRY(hipMalloc(&c->send, 2 * c->cap * PHYS_HALO_BODY_RECORD_BYTES));
+    PHYS_HIP_TRY(hipMalloc(&c->recv, (size_t)std::max(c->n_ranks, 2) * c->cap * PHYS_HALO_BODY_RECORD_BYTES));
     return PHYS_OK;
 }
 
 // pack -> [all-gather] -> unpack of one world; `gather` is skipped when the caller groups the collectives itself
 static int32_t exchange_front(phys_world* w, phys_comm* c, size_t* bytes_per_rank) {
     const bool ghosts = w->max_ghosts > 0;
-    *bytes_per_rank = c->cap * (ghosts ? (size_t)PHYS_HALO_BODY_RECORD_BYTES : (size_t)32);
-    if (ghosts) return halo_pack_bodies(w, c->send, c->cap);
-    return halo_pack(w, w->slab_lo, w->slab_hi, w->slab_reach, c->send, c->cap, nullptr);
+    const size_t rec = ghosts ? (size_t)PHYS_HALO_BODY_RECORD_BYTES : (size_t)32;
+    *bytes_per_rank = c->cap * rec;
+    if (!c->neighbours) {
+        if (ghosts) return halo_pack_bodies(w, c->send, c->cap);
+        return halo_pack(w, w->slab_lo, w->slab_hi, w->slab_reach, c->send, c->cap, nullptr);
+    }
+    // one block per face: what rank - 1 may need lies within reach of the low face, what rank + 1 may need of the high one
+    const float far = 3.0e38f;
+    char* send = static_cast<char*>(c->send);
+    const size_t block = c->cap * rec;
+    int32_t rc = PHYS_OK;
+    if (c->rank > 0)
+        rc = ghosts ? halo_pack_bodies_faces(w, send, c->cap, w->slab_lo, far)
+                    : halo_pack(w, w->slab_lo, far, w->slab_reach, send, c->cap, nullptr);
+    if (rc == PHYS_OK && c->rank + 1 < c->n_ranks)
+        rc = ghosts ? halo_pack_bodies_faces(w, send + block, c->cap, -far, w->slab_hi)
+                    : halo_pack(w, -far, w->slab_hi, w->slab_reach, send + block, c->cap, nullptr);
+    return rc;
 }
 static int32_t exchange_back(phys_world* w, phys_comm* c) {
-    const uint64_t total = (uint64_t)c->n_ranks * c->cap, own = (uint64_t)c->rank * c->cap;
-    if (w->max_ghosts > 0) return halo_unpack_ghosts(w, c->recv, total, own, c->cap);
-    return halo_pairs(w, c->recv, total, own, c->cap, nullptr);
+    // all-gather: n blocks, this rank's own one skipped; neighbours: the two received blocks, nothing to skip
+    const uint64_t total = (uint64_t)(c->neighbours ? 2 : c->n_ranks) * c->cap;
+    const uint64_t own = c->neighbours ? 0 : (uint64_t)c->rank * c->cap, own_count = c->neighbours ? 0 : c->cap;
+    if (w->max_ghosts > 0) return halo_unpack_ghosts(w, c->recv, total, own, own_count);
+    return halo_pairs(w, c->recv, total, own, own_count, nullptr);
+}
+// the collective(s) of one rank, to be called between ncclGroupStart / ncclGroupEnd when there are several per thread
+static int exchange_wire(phys_world* w, phys_comm* c, size_t bytes) {
+    if (!c->neighbours) return rccl().AllGather(c->send, c->recv, bytes, kNcclUint8, c->comm, w->stream);
+    char* recv = static_cast<char*>(c->recv);
+    const size_t block = bytes;  // blocks are packed at the size of the records in use (96-byte bodies or 32-byte AABBs)
+    int nr = 0;
+    const char* send = static_cast<const char*>(c->send);
+    if (c->rank > 0) {
+        nr = rccl().Send(send, bytes, kNcclUint8, c->rank - 1, c->comm, w->stream);
+        if (nr == 0) nr = rccl().Recv(recv, bytes, kNcclUint8, c->rank - 1, c->comm, w->stream);
+    }
+    if (nr == 0 && c->rank + 1 < c->n_ranks) {
+        nr = rccl().Send(send + block, bytes, kNcclUint8, c->rank + 1, c->comm, w->stream);
+        if (nr == 0) nr = rccl().Recv(recv + block, bytes, kNcclUint8, c->rank + 1, c->comm, w->stream);
+    }
+    return nr;
 }
 
 extern "C" {
@@ -197,9 +241,27 @@ int32_t phys_halo_exchange(phys_world* w, phys_comm* c) {
     size_t bytes = 0;
     int32_t rc = exchange_front(w, c, &bytes);
     if (rc != PHYS_OK) return rc;
-    const int nr = rccl().AllGather(c->send, c->recv, bytes, kNcclUint8, c->comm, w->stream);
-    if (nr != 0) return rccl_fail("ncclAllGather", nr);
+    int nr = 0;
+    if (c->neighbours) {  // up to two send / receive pairs: one group, or they would wait for each other
+        nr = rccl().GroupStart();
+        if (nr != 0) return rccl_fail("ncclGroupStart", nr);
+        nr = exchange_wire(w, c, bytes);
+        const int ne = rccl().GroupEnd();
+        if (nr == 0) nr = ne;
+    } else {
+        nr = exchange_wire(w, c, bytes);
+    }
+    if (nr != 0) return rccl_fail(c->neighbours ? "ncclSend / ncclRecv" : "ncclAllGather", nr);
     return exchange_back(w, c);
+}
+
+int32_t phys_comm_set_neighbours(phys_comm* c, int32_t enable) {
+    if (!c) { set_error("null argument"); return PHYS_ERR_INVALID_ARG; }
+    PHYS_HIP_TRY(hipSetDevice(c->device));
+    c->neighbours = enable != 0;
+    // a block nobody sends into (first / last rank, or one rank alone) reads as "no records" for ever
+    if (c->neighbours) PHYS_HIP_TRY(hipMemset(c->recv, 0xFF, (size_t)2 * c->cap * PHYS_HALO_BODY_RECORD_BYTES));
+    return PHYS_OK;
 }
 
 // one process, n worlds on n devices: the n collectives of a step must be issued as ONE group
@@ -214,8 +276,8 @@ int32_t phys_halo_exchange_all(phys_world** worlds, phys_comm** comms, int32_t n
     int nr = rccl().GroupStart();
     if (nr != 0) return rccl_fail("ncclGroupStart", nr);
     for (int32_t k = 0; k < n; ++k) {
-        nr = rccl().AllGather(comms[k]->send, comms[k]->recv, bytes[k], kNcclUint8, comms[k]->comm, worlds[k]->stream);
-        if (nr != 0) { (void)rccl().GroupEnd(); return rccl_fail("ncclAllGather", nr); }
+        nr = exchange_wire(worlds[k], comms[k], bytes[k]);
+        if (nr != 0) { (void)rccl().GroupEnd(); return rccl_fail("halo exchange", nr); }
     }
     nr = rccl().GroupEnd();
     if (nr != 0) return rccl_fail("ncclGroupEnd", nr);

@@ -317,6 +317,12 @@ static int32_t halo_counts_room(phys_world* w, uint64_t items) {
 }
 
 int32_t halo_pack_bodies(phys_world* w, void* dev_out, uint64_t cap) {
+    return halo_pack_bodies_faces(w, dev_out, cap, w->slab_lo, w->slab_hi);
+}
+
+// the bodies within reach of the given faces only (a neighbour exchange packs one block per face: the other face is
+// moved out of the way)
+int32_t halo_pack_bodies_faces(phys_world* w, void* dev_out, uint64_t cap, float x_lo, float x_hi) {
     if (!dev_out) { set_error("null argument"); return PHYS_ERR_INVALID_ARG; }
     if (w->max_ghosts == 0) { set_error("world created without phys_config.max_ghosts"); return PHYS_ERR_UNSUPPORTED; }
     if (!(w->slab_reach > 0.0f)) { set_error("phys_set_slab first"); return PHYS_ERR_UNSUPPORTED; }
@@ -329,9 +335,9 @@ int32_t halo_pack_bodies(phys_world* w, void* dev_out, uint64_t cap) {
     if (n) {
         const dim3 g((n + 255) / 256), b(256);
         hipLaunchKernelGGL(k_halo_count<0>, g, b, 0, w->stream, n, n, w->pos.p, w->shape.p, (const BodyRecord*)nullptr, 0u, 0u,
-                           w->slab_lo, w->slab_hi, w->slab_reach, w->halo_block_counts.p);
+                           x_lo, x_hi, w->slab_reach, w->halo_block_counts.p);
         hipLaunchKernelGGL(k_halo_pack_bodies, g, b, 0, w->stream, n, w->pos.p, w->rot.p, w->vel.p, w->half_extent.p, w->shape.p,
-                           w->global_id.p, w->slab_lo, w->slab_hi, w->slab_reach, w->halo_block_counts.p, (BodyRecord*)dev_out,
+                           w->global_id.p, x_lo, x_hi, w->slab_reach, w->halo_block_counts.p, (BodyRecord*)dev_out,
                            (uint32_t)cap, w->counters.p);
     }
     PHYS_HIP_TRY(hipGetLastError());

@@ -147,6 +147,7 @@ void launch_solve_cluster(phys_world* w, void* row_all, uint64_t cap, float fric
                           bool diag, long long timeout_ticks);
 
 int32_t halo_pack_bodies(phys_world* w, void* dev_out, uint64_t cap);
+int32_t halo_pack_bodies_faces(phys_world* w, void* dev_out, uint64_t cap, float x_lo, float x_hi);
 int32_t halo_unpack_ghosts(phys_world* w, const void* dev_records, uint64_t n_records, uint64_t skip_first, uint64_t skip_count);
 
 }  // namespace phys

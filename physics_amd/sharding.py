@@ -175,15 +175,21 @@ class _BenchHalo:
 
 def make_rank_scene(workload, rank, world_size, dist, local_rank, pinned_host=False):
     sc, x_lo, x_hi, gids = rank_scene(workload, rank, world_size)
-    # boundary layers: two lattice layers per face is generous; 4x headroom
-    ny_nz = sc.n // {"c1": 4, "c2": 25, "c3": 50, "c4": 100, "c5": 16, "t1m": 100}[workload]
-    cap = max(4096, 16 * ny_nz)
+    # records per slab face and step: the bodies that start within reach of it, with 1.5x headroom for what the pile does
+    # later (a block is sent whole: capacity is bandwidth), never fewer than 4096
+    reach = static_reach(sc.half_extent, sc.config().contact_margin)
+    x = sc.pos[:, 0]
+    near = max(int(np.count_nonzero(x < x_lo + reach)), int(np.count_nonzero(x > x_hi - reach)))
+    cap = max(4096, near + near // 2)
     if sc.flags & scenes.FLAG_BROADPHASE_ONLY:
         halo = HaloExchange(dist, rank, world_size, f"cuda:{local_rank}", cap, pinned_host=pinned_host)
         return sc, _BenchHalo(halo, x_lo, x_hi, gids, before_update=False)
     # full step: neighbours' boundary bodies become ghosts of this rank (contacts across the cut planes)
     sc.cfg_overrides["max_ghosts"] = 2 * cap
-    halo = GhostExchange(dist, rank, world_size, cap, transport="host" if pinned_host else "rccl")
+    # the rank scenes are slabs side by side along x in rank order, each far wider than the reach: neighbours only, one
+    # block per face (the host transport of the rehearsal gathers one block holding both faces)
+    halo = GhostExchange(dist, rank, world_size, 2 * cap if pinned_host else cap, transport="host" if pinned_host else "rccl",
+                         neighbours=True)
     return sc, _BenchHalo(halo, x_lo, x_hi, gids, before_update=True)
 
 
@@ -197,10 +203,14 @@ class GhostExchange:
     transport "host": the same pack / unpack entry points around a torch.distributed all_gather on pinned host
     buffers (gloo): the CPU tests with a stand-in world, and the rehearsal of N ranks on a one-GPU box."""
 
-    def __init__(self, dist, rank, world_size, cap, transport="rccl"):
+    def __init__(self, dist, rank, world_size, cap, transport="rccl", neighbours=False):
+        """neighbours (rccl transport): the ranks are x-slabs ordered by rank and none is thinner than the reach, so a rank
+        exchanges with ranks r - 1 and r + 1 only (phys_comm_set_neighbours) - two point-to-point messages over direct
+        xGMI links instead of an all-gather of every rank's block."""
         import torch
         self.torch, self.dist, self.rank, self.world_size, self.cap = torch, dist, rank, world_size, int(cap)
         self.transport = transport
+        self.neighbours = bool(neighbours)
         self.comm = None
         self.x_lo = self.x_hi = self.reach = 0.0
         if transport == "host":
@@ -223,7 +233,7 @@ class GhostExchange:
                 self.comm.close()
             ids = [Comm.unique_id() if self.rank == 0 else None]
             self.dist.broadcast_object_list(ids, src=0)
-            self.comm = Comm(world, ids[0], self.rank, self.world_size, self.cap)
+            self.comm = Comm(world, ids[0], self.rank, self.world_size, self.cap, neighbours=self.neighbours)
 
     def move_slab(self, world, x_lo, x_hi):
         self.x_lo, self.x_hi = float(x_lo), float(x_hi)

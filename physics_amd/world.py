@@ -222,6 +222,10 @@ class World:
     def halo_pack_bodies(self, dev_ptr, cap):
         self._ck(self.lib.phys_halo_pack_bodies(self.h, C.c_void_p(dev_ptr), cap))
 
+    def halo_pack_bodies_face(self, dev_ptr, cap, face):
+        """face < 0: bodies within reach of the low slab face only, > 0: of the high face, 0: both."""
+        self._ck(self.lib.phys_halo_pack_bodies_face(self.h, C.c_void_p(dev_ptr), cap, int(face)))
+
     def halo_unpack_ghosts(self, dev_ptr, n_records, skip_first=0, skip_count=0):
         self._ck(self.lib.phys_halo_unpack_ghosts(self.h, C.c_void_p(dev_ptr), n_records, skip_first, skip_count))
 
@@ -247,14 +251,20 @@ class Comm:
             raise PhysError(rc, lib.phys_last_error().decode())
         return bytes(buf)
 
-    def __init__(self, world, unique_id, rank, n_ranks, capacity):
+    def __init__(self, world, unique_id, rank, n_ranks, capacity, neighbours=False):
+        """neighbours: the ranks are x-slabs ordered by rank, none thinner than the reach - exchange with ranks r - 1 and
+        r + 1 only (phys_comm_set_neighbours) instead of an all-gather of every rank's block."""
         self.lib = world.lib
         self.h = C.c_void_p()
-        self.rank, self.n_ranks, self.capacity = rank, n_ranks, capacity
+        self.rank, self.n_ranks, self.capacity, self.neighbours = rank, n_ranks, capacity, bool(neighbours)
         buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
         rc = self.lib.phys_comm_create(world.h, buf, rank, n_ranks, capacity, C.byref(self.h))
         if rc != 0:
             raise PhysError(rc, self.lib.phys_last_error().decode())
+        if neighbours:
+            rc = self.lib.phys_comm_set_neighbours(self.h, 1)
+            if rc != 0:
+                raise PhysError(rc, self.lib.phys_last_error().decode())
 
     def close(self):
         if getattr(self, "h", None):

@@ -139,6 +139,7 @@ extern "C" {
     pub fn phys_get_cross_pairs(w: *mut phys_world, pairs_out: *mut u32, cap: u64, n_pairs: *mut u64) -> i32;
     pub fn phys_set_slab(w: *mut phys_world, x_lo: f32, x_hi: f32, reach: f32) -> i32;
     pub fn phys_halo_pack_bodies(w: *mut phys_world, dev_records_out: *mut c_void, cap: u64) -> i32;
+    pub fn phys_halo_pack_bodies_face(w: *mut phys_world, dev_records_out: *mut c_void, cap: u64, face: i32) -> i32;
     pub fn phys_halo_unpack_ghosts(w: *mut phys_world, dev_records: *const c_void, n_records: u64, skip_first: u64,
                                    skip_count: u64) -> i32;
     pub fn phys_get_global_ids(w: *mut phys_world, out: *mut u32) -> i32;
@@ -147,6 +148,7 @@ extern "C" {
                             out: *mut *mut phys_comm) -> i32;
     pub fn phys_comm_create_local(worlds: *mut *mut phys_world, n: i32, capacity: u64, comms_out: *mut *mut phys_comm) -> i32;
     pub fn phys_comm_destroy(c: *mut phys_comm) -> i32;
+    pub fn phys_comm_set_neighbours(c: *mut phys_comm, enable: i32) -> i32;
     pub fn phys_halo_exchange(w: *mut phys_world, c: *mut phys_comm) -> i32;
     pub fn phys_halo_exchange_all(worlds: *mut *mut phys_world, comms: *mut *mut phys_comm, n: i32) -> i32;
     pub fn phys_slab_histogram(pos: *const f32, n: u64, x_min: f32, x_max: f32, bins: u32, hist: *mut u64) -> i32;

@@ -29,7 +29,7 @@ def _make(pos, vel, gids, x_lo, x_hi, ground, cap, gravity=(0.0, -9.81, 0.0)):
 class TwoRanks:
     """Left world owns x < 0, right world x >= 0; exchange() plays the all-gather with device copies."""
 
-    def __init__(self, pos, vel, ground=True, exchange=True, cap=1024, gravity=(0.0, -9.81, 0.0)):
+    def __init__(self, pos, vel, ground=True, exchange=True, cap=1024, gravity=(0.0, -9.81, 0.0), neighbours=False):
         import torch
         self.torch = torch
         left = pos[:, 0] < 0
@@ -39,12 +39,27 @@ class TwoRanks:
         self.cap = cap
         self.send = [torch.empty(cap * REC, dtype=torch.uint8, device="cuda") for _ in range(2)]
         self.do_exchange = exchange
+        self.neighbours = neighbours  # the blocks a neighbour exchange (phys_comm_set_neighbours) moves: one per face
         self.n_total = len(pos)
 
     def step(self, k=1):
         torch = self.torch
         for _ in range(k):
-            if self.do_exchange:
+            if self.do_exchange and self.neighbours:
+                # rank 0 sends its HIGH-face block to rank 1, rank 1 its LOW-face block to rank 0; a rank scans two
+                # received blocks {from r - 1, from r + 1}, the missing one empty (0xFF), and skips nothing
+                self.worlds[0].halo_pack_bodies_face(self.send[0].data_ptr(), self.cap, +1)
+                self.worlds[1].halo_pack_bodies_face(self.send[1].data_ptr(), self.cap, -1)
+                for w in self.worlds:
+                    w.sync()
+                empty = torch.full_like(self.send[0], 0xFF)
+                recv = [torch.cat([empty, self.send[1]]), torch.cat([self.send[0], empty])]
+                torch.cuda.synchronize()
+                for w, blocks in zip(self.worlds, recv):
+                    w.halo_unpack_ghosts(blocks.data_ptr(), 2 * self.cap, 0, 0)
+                for w in self.worlds:
+                    w.sync()
+            elif self.do_exchange:
                 for w, buf in zip(self.worlds, self.send):
                     w.halo_pack_bodies(buf.data_ptr(), self.cap)
                 for w in self.worlds:
@@ -140,6 +155,22 @@ def test_piles_meeting_at_the_plane_do_not_interpenetrate_and_runs_repeat_bit_fo
     control.close()
 
 
+def test_neighbour_blocks_give_the_same_run_as_the_all_gather():
+    """phys_comm_set_neighbours sends one block per slab face to the rank beyond it instead of gathering every rank's
+    block everywhere. With two ranks both move the same bodies, so the sharded run must repeat the all-gather run bit
+    for bit (the ghosts arrive in the same order: ordered compaction of one block)."""
+    pos, vel = _two_piles()
+    runs = []
+    for neighbours in (False, True):
+        t = TwoRanks(pos, vel, neighbours=neighbours)
+        t.step(120)
+        assert sum(w.get_stats().n_ghosts for w in t.worlds) > 0
+        runs.append(t.state())
+        t.close()
+    for a, b in zip(runs[0], runs[1]):
+        assert np.array_equal(a, b), "per-face blocks changed the sharded run"
+
+
 def test_ghost_capacity_overflow_is_reported():
     import physics_amd
     pos, vel = _two_piles()
@@ -168,12 +199,14 @@ def test_rccl_exchange_behind_the_c_abi_with_one_rank():
     import physics_amd
     pos, vel = _two_piles()
     w = _make(pos, vel, np.arange(len(pos), dtype=np.uint32), -2.0, 2.0, True, 256)
-    comm = physics_amd.Comm(w, physics_amd.Comm.unique_id(), 0, 1, 256)
-    for _ in range(80):  # long enough for the lowest layer to land
-        w.halo_exchange(comm)
-        w.update(DT)
-    w.sync()
-    st = w.get_stats()
-    assert st.n_ghosts == 0 and st.overflow == 0 and st.n_manifolds > 0
-    comm.close()
+    for neighbours in (False, True):  # all-gather / grouped ncclSend + ncclRecv per neighbour (none with one rank)
+        comm = physics_amd.Comm(w, physics_amd.Comm.unique_id(), 0, 1, 256, neighbours=neighbours)
+        for _ in range(40):  # long enough for the lowest layer to land
+            w.halo_exchange(comm)
+            w.update(DT)
+        w.sync()
+        st = w.get_stats()
+        assert st.n_ghosts == 0 and st.overflow == 0
+        comm.close()
+    assert st.n_manifolds > 0
     w.close()
