@@ -54,7 +54,7 @@ int32_t cluster_assign(phys_world* w, const float* pos /* host, 3 * n_owned */) 
     w->cluster_count = 0;
     const uint64_t n = w->n, n_owned = w->n_owned;
     static const bool off = getenv("PHYS_DEBUG_NO_CLUSTER") != nullptr;
-    if (off || n < kClusterMinBodies || !w->flow_vel.p) return PHYS_OK;
+    if (off || n_owned < kClusterMinBodies || !w->flow_vel.p) return PHYS_OK;
     int cus = 0;
     PHYS_HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, w->device));
     // one workgroup per cluster, several per CU (their phases interleave: one waits for its rows while the others
@@ -69,35 +69,34 @@ int32_t cluster_assign(phys_world* w, const float* pos /* host, 3 * n_owned */) 
     // allocation units), or the grid would not be resident: fewer, larger clusters per CU until it does
     for (;; --per_cu) {
         const uint32_t max_clusters = (uint32_t)std::max(8, per_cu * (cus - (spare_div ? cus / spare_div : 0)));
-        slots = (uint32_t)((n + max_clusters - 1) / max_clusters);
+        slots = (uint32_t)((n_owned + max_clusters - 1) / max_clusters);
         slots = (slots + 63u) / 64u * 64u;
         const size_t per_wg = (cluster_lds_bytes(slots) + 1023) / 1024 * 1024;
         if (per_wg * (size_t)per_cu <= kClusterLdsPerCu && slots <= kClusterMaxSlots) break;
         if (per_cu == 1) return PHYS_OK;  // the bodies would not fit the CU's LDS: per-colour launches
     }
-    const uint32_t clusters = (uint32_t)((n + slots - 1) / slots);
-    // isotropic Morton key over the bounding box of the owned bodies (ghost slots: behind everybody)
+    const uint32_t clusters = (uint32_t)((n_owned + slots - 1) / slots);
+    // isotropic Morton key over the bounding box of the owned bodies. Ghost bodies (sharded worlds) get no home in
+    // any cluster: a row never has one as body A, as body B it is 'another cluster's body' for everybody (slot ~0 maps
+    // to a cluster nobody runs), and no workgroup is spent on clusters that own no rows
     float lo[3] = {3e38f, 3e38f, 3e38f}, hi[3] = {-3e38f, -3e38f, -3e38f};
     for (uint64_t i = 0; i < n_owned; ++i)
         for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], pos[3 * i + a]); hi[a] = std::max(hi[a], pos[3 * i + a]); }
     const float span = std::max(std::max(hi[0] - lo[0], hi[1] - lo[1]), std::max(hi[2] - lo[2], 1e-6f));
     const float scale = 1023.0f / span;
-    std::vector<uint64_t> keyed(n);
-    for (uint64_t i = 0; i < n; ++i) {
-        uint64_t key = 0x40000000ull;  // ghosts
-        if (i < n_owned) {
-            uint32_t q[3];
-            for (int a = 0; a < 3; ++a) {
-                const float t = (pos[3 * i + a] - lo[a]) * scale;
-                q[a] = t <= 0.0f ? 0u : (t >= 1023.0f ? 1023u : (uint32_t)t);
-            }
-            key = spread10(q[0]) | (spread10(q[1]) << 1) | (spread10(q[2]) << 2);
+    std::vector<uint64_t> keyed(n_owned);
+    for (uint64_t i = 0; i < n_owned; ++i) {
+        uint32_t q[3];
+        for (int a = 0; a < 3; ++a) {
+            const float t = (pos[3 * i + a] - lo[a]) * scale;
+            q[a] = t <= 0.0f ? 0u : (t >= 1023.0f ? 1023u : (uint32_t)t);
         }
+        const uint64_t key = spread10(q[0]) | (spread10(q[1]) << 1) | (spread10(q[2]) << 2);
         keyed[i] = (key << 32) | i;
     }
     std::sort(keyed.begin(), keyed.end());
-    std::vector<uint32_t> cslot(n), body_of((size_t)clusters * slots, 0xFFFFFFFFu);
-    for (uint64_t r = 0; r < n; ++r) {
+    std::vector<uint32_t> cslot(n, 0xFFFFFFFFu), body_of((size_t)clusters * slots, 0xFFFFFFFFu);
+    for (uint64_t r = 0; r < n_owned; ++r) {
         const uint32_t i = (uint32_t)keyed[r];
         cslot[i] = (uint32_t)r;  // = cluster * slots + slot
         body_of[r] = i;

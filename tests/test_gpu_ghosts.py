@@ -171,6 +171,64 @@ def test_neighbour_blocks_give_the_same_run_as_the_all_gather():
         assert np.array_equal(a, b), "per-face blocks changed the sharded run"
 
 
+def test_cluster_solver_with_ghosts_equals_the_per_colour_kernels():
+    """Two 16 x 130 x 16 towers side by side, one per rank, in contact across the plane: dense enough for the cluster
+    solver (cluster.hip), which gives ghost bodies no home in any cluster (for every row they are 'another cluster's
+    body'). The same sharded run with the per-colour kernels forced (PHYS_FLAG_SOLVER_PER_COLOR) must give the same
+    bits, and the cluster solver must really have run."""
+    import physics_amd
+    import torch
+    from physics_amd import scenes
+    sc = scenes.c5(16, 130, 16)
+    width = float(sc.pos[:, 0].max() - sc.pos[:, 0].min()) + 2.0  # lattice spacing of the tower: 2.0
+    results = []
+    for flags_extra in (0, physics_amd.FLAG_SOLVER_PER_COLOR):
+        worlds, sends = [], []
+        cap = 8192
+        for r in range(2):
+            cfg = sc.config(flags=sc.flags | flags_extra, max_ghosts=2 * cap)
+            w = physics_amd.World(cfg)
+            pos = sc.pos.copy()
+            pos[:, 0] += np.float32(r * width)
+            w.set_bodies(pos, shape_type=sc.shape_type, half_extent=sc.half_extent)
+            w.set_global_ids((np.arange(sc.n) + r * sc.n).astype(np.uint32))
+            lo = float(sc.pos[:, 0].min()) - 1.0 + r * width
+            w.set_slab(lo if r else -1.0e6, lo + width if r == 0 else 1.0e6, 4.0)
+            worlds.append(w)
+            sends.append(torch.empty(cap * REC, dtype=torch.uint8, device="cuda"))
+        empty = torch.full_like(sends[0], 0xFF)
+        ran_cluster = False
+        for step in range(14):
+            worlds[0].halo_pack_bodies_face(sends[0].data_ptr(), cap, +1)
+            worlds[1].halo_pack_bodies_face(sends[1].data_ptr(), cap, -1)
+            for w in worlds:
+                w.sync()
+            recv = [torch.cat([empty, sends[1]]), torch.cat([sends[0], empty])]
+            torch.cuda.synchronize()
+            for w, blocks in zip(worlds, recv):
+                w.halo_unpack_ghosts(blocks.data_ptr(), 2 * cap, 0, 0)
+            for w in worlds:
+                w.sync()
+            if step == 10:
+                worlds[0].profile_enable(True)
+            for w in worlds:
+                w.update(DT)
+        for w in worlds:
+            w.sync()
+        prof, _ = worlds[0].profile_get()
+        ran_cluster = "solve_cluster" in prof
+        st = [w.get_stats() for w in worlds]
+        assert all(s.overflow == 0 for s in st) and all(s.n_ghosts > 0 for s in st)
+        ids = worlds[0].get_manifolds()[0]
+        assert ((ids[:, 1] >= st[0].n_bodies) & (ids[:, 1] != 0xFFFFFFFF)).any(), "no contact against a ghost"
+        assert ran_cluster == (flags_extra == 0), f"solver path: {sorted(prof)}"
+        results.append([a for w in worlds for a in w.get_transforms() + w.get_velocities()])
+        for w in worlds:
+            w.close()
+    for a, b in zip(results[0], results[1]):
+        assert np.array_equal(a, b), "cluster solver with ghosts differs from the per-colour kernels"
+
+
 def test_ghost_capacity_overflow_is_reported():
     import physics_amd
     pos, vel = _two_piles()
