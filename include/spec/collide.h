@@ -39,13 +39,16 @@ typedef struct {
     float depth[4];
 } manifold_t;
 
-/* per-lane scratch of the polygon clipper: 224 bytes. The HIP narrow phase keeps it in LDS (one slice per
- * lane, odd dword stride) instead of private scratch memory; the oracle puts it on the stack. */
+/* per-lane scratch of the polygon clipper: 192 bytes. The HIP narrow phase keeps it in LDS (one slice per
+ * lane, odd dword stride) instead of private scratch memory; the oracle puts it on the stack. The depths of the
+ * candidate points live in polyB, which is free by the time they are made (candidates are compacted in place in
+ * polyA): at 49 dwords per lane three 256-thread workgroups fit a CU's LDS instead of two, and the narrow phase is
+ * bound by how many dependent memory round trips its few resident waves can overlap. */
 typedef struct {
     v3 polyA[8];
     v3 polyB[8];
-    float dep[8];
 } clip_ws_t;
+PHYS_HD float* clip_ws_depths(clip_ws_t* ws) { return &ws->polyB[0].x; }
 
 PHYS_HD geom_t geom_make(v3 c, quat q, v3 h, uint32_t type) {
     geom_t g;
@@ -248,8 +251,8 @@ PHYS_HD void box_face_contact(const geom_t* Ref, const geom_t* Inc, int r, float
     n = clip_poly(polyB, n, Ref->c, v3_neg(u1), l1, polyA);
     n = clip_poly(polyA, n, Ref->c, u2, l2, polyB);
     n = clip_poly(polyB, n, Ref->c, v3_neg(u2), l2, polyA);
-    /* keep points at or below the reference face (+ margin); the final polygon is in polyA, so polyB is free */
-    v3* cand = ws->polyB; float* cdep = ws->dep; int nc = 0;
+    /* keep points at or below the reference face (+ margin): compacted in place (nc <= k), depths into the free polyB */
+    v3* cand = ws->polyA; float* cdep = clip_ws_depths(ws); int nc = 0;
     const float hr = v3_get(Ref->h, r);
     for (int k = 0; k < 8; ++k) {
         if (k >= n) break;
@@ -397,7 +400,7 @@ PHYS_HD void collide_ground(const geom_t* A, float ground, float margin, manifol
         m->pt[0] = v3_make(A->c.x, bottom + 0.5f * depth, A->c.z);
         m->depth[0] = depth;
     } else if (A->type == PHYS_SPEC_SHAPE_BOX) {
-        v3* cand = ws->polyA; float* cdep = ws->dep; int nc = 0;
+        v3* cand = ws->polyA; float* cdep = clip_ws_depths(ws); int nc = 0;
         const v3 ex = v3_scale(m33_col(&A->R, 0), A->h.x);
         const v3 ey = v3_scale(m33_col(&A->R, 1), A->h.y);
         const v3 ez = v3_scale(m33_col(&A->R, 2), A->h.z);

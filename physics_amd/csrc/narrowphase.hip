@@ -61,6 +61,9 @@ __global__ __launch_bounds__(kNpThreads) void k_narrowphase(
         manifold_t m;
         m.count = 0;
         uint32_t a = 0, b = PHYS_GROUND_ID;
+        ulonglong2 early = make_ulonglong2(0ull, 0ull);
+        uint32_t early_h = 0;
+        bool have_early = false;
         if (idx < n_ground) {
             a = idx;
             // the fattened AABB of this step (k_step_velocity_aabb; lo.y = lowest corner - margin) rules most bodies out
@@ -75,6 +78,14 @@ __global__ __launch_bounds__(kNpThreads) void k_narrowphase(
             const uint2 pr = reinterpret_cast<const uint2*>(pairs)[idx - n_ground];
             a = pr.x; b = pr.y;
             if (a < n_owned) {  // a < b: both are ghosts iff a is one
+                // the colour-table entry this pair would keep its colour from (a random 16-byte read): asked for NOW, so
+                // that it travels while the shapes are fetched and tested instead of being one more dependent round trip
+                // behind the emission below (nearly every candidate pair of a resting pile becomes a manifold)
+                if (cache_mask) {
+                    early_h = (uint32_t)(color_priority(a, b) >> 20) & cache_mask;
+                    early = cache[early_h];
+                    have_early = true;
+                }
                 const geom_t ga = load_geom(a, pos, rot, half_extent, shape);
                 const geom_t gb = load_geom(b, pos, rot, half_extent, shape);
                 collide_pair(&ga, &gb, margin, &m, ws);
@@ -128,7 +139,8 @@ __global__ __launch_bounds__(kNpThreads) void k_narrowphase(
                     const unsigned long long key = ((unsigned long long)a << 32) | b;
                     uint32_t h = (uint32_t)(prio >> 20) & cache_mask;
                     for (;;) {
-                        const ulonglong2 e = cache[h];
+                        const ulonglong2 e = (have_early && h == early_h) ? early : cache[h];
+                        have_early = false;
                         if (e.x == key) {
                             if ((uint32_t)(e.y >> 32) + 1u == stamp) {
                                 col = (uint32_t)e.y;
@@ -155,6 +167,9 @@ __global__ __launch_bounds__(kNpThreads) void k_narrowphase(
                     atomicMax(&top0[a], prio);
                     if (b != PHYS_GROUND_ID) atomicMax(&top0[b], prio);
                 }
+                // (Measured and dropped: staging the records of a wave in LDS and copying them out as whole 128-byte lines -
+                // 4.5 write requests per manifold become 2 - left the kernel at 0.52 ms on C5: it waits on its chain of
+                // dependent round trips - pair, shapes, slot atomic, table entry, used masks - not on the write path.)
                 float4* o = reinterpret_cast<float4*>(man_geo) + 8 * slot;  // one 128-byte line per manifold, 96 bytes used
                 o[0] = make_float4(__uint_as_float(a), __uint_as_float(b), __uint_as_float((uint32_t)m.count),
                                    __uint_as_float(col != kUncolored ? 1u : 0u) /* colour kept: already in the table */);
