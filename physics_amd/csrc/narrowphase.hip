@@ -438,34 +438,57 @@ __global__ __launch_bounds__(1024) void k_color_hist(uint64_t max_manifolds, con
 
 // one workgroup: exclusive scan of block_hist in colour-major order (in place) + per-colour totals
 __global__ __launch_bounds__(1024) void k_color_offsets(uint32_t* __restrict__ block_hist, uint32_t nb, StepCounters* __restrict__ ctr) {
-    // every thread owns a run of consecutive entries: sum, one block-wide scan of the 1024 sums, then the run again
-    // (one pass instead of kTotal / 1024 dependent ones: 38 -> ~6 us at 512 workgroups)
+    // every WAVE owns a run of consecutive entries, read 64 at a time (coalesced, all loads in flight at once), scanned
+    // with shuffles and a running carry; then one scan of the 16 wave totals (38 us for the 32 dependent block-wide passes
+    // of the first version at 512 workgroups, 59 us with a run per THREAD - 32 dependent uncoalesced loads - 8 us so)
     __shared__ uint32_t wtot[16];
     __shared__ uint32_t carry_s;
     const uint32_t kPerColor = nb;
-    const uint32_t kTotal = PHYS_MAX_COLORS * kPerColor;
-    const uint32_t per = (kTotal + 1023u) / 1024u;
-    const uint32_t begin = threadIdx.x * per < kTotal ? threadIdx.x * per : kTotal;
-    const uint32_t end = begin + per < kTotal ? begin + per : kTotal;
-    uint32_t sum = 0;
-    for (uint32_t i = begin; i < end; ++i) sum += block_hist[i];
-    uint32_t inc = sum;
-    const int lane = threadIdx.x & 63;
+    const uint32_t kTotal = PHYS_MAX_COLORS * kPerColor;   // <= 64 * 512
+    const uint32_t per_wave = (kTotal + 15u) / 16u;        // nb is a power of two: a multiple of 4
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t w_begin = wave * per_wave < kTotal ? wave * per_wave : kTotal;
+    const uint32_t w_end = w_begin + per_wave < kTotal ? w_begin + per_wave : kTotal;
+    constexpr int kTrips = (PHYS_MAX_COLORS * kSortBlocksMax / 16 + 63) / 64;  // 32, eight at a time (registers)
+    constexpr int kHalf = kTrips / 4;
+    uint32_t v[kHalf];
+    uint32_t run = 0;  // sum of this wave's entries in front of the current trip
+    // pass 1: the wave's total; pass 2 (after the scan of the wave totals): the exclusive offsets, written in place
+    for (int pass = 0; pass < 2; ++pass) {
+        uint32_t base = 0;
+        if (pass == 1) {
+            if (lane == 0) wtot[wave] = run;
+            __syncthreads();
+            for (uint32_t k = 0; k < wave; ++k) base += wtot[k];
+            if (threadIdx.x == 1023) carry_s = base + run;
+            run = 0;
+        }
+        for (int half = 0; half < 4; ++half) {
+            const uint32_t h_begin = w_begin + (uint32_t)(half * kHalf) * 64u;
+            if (h_begin >= w_end) break;  // wave-uniform
 #pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t o = (uint32_t)__shfl_up((int)inc, off, 64);
-        if (lane >= off) inc += o;
-    }
-    if (lane == 63) wtot[threadIdx.x >> 6] = inc;
-    __syncthreads();
-    uint32_t running = inc - sum;
-    for (uint32_t k = 0; k < (threadIdx.x >> 6); ++k) running += wtot[k];
-    if (threadIdx.x == 1023) carry_s = running + sum;
-    for (uint32_t i = begin; i < end; ++i) {
-        const uint32_t v = block_hist[i];
-        block_hist[i] = running;
-        if (i % kPerColor == 0) ctr->color_start[i / kPerColor] = running;
-        running += v;
+            for (int k = 0; k < kHalf; ++k) {
+                const uint32_t i = h_begin + (uint32_t)k * 64u + lane;
+                v[k] = i < w_end ? block_hist[i] : 0u;
+            }
+#pragma unroll
+            for (int k = 0; k < kHalf; ++k) {
+                uint32_t inc = v[k];
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const uint32_t o = (uint32_t)__shfl_up((int)inc, off, 64);
+                    if (lane >= (uint32_t)off) inc += o;
+                }
+                const uint32_t total = (uint32_t)__shfl((int)inc, 63, 64);
+                const uint32_t i = h_begin + (uint32_t)k * 64u + lane;
+                if (pass == 1 && i < w_end) {
+                    const uint32_t excl = base + run + inc - v[k];
+                    block_hist[i] = excl;
+                    if (i % kPerColor == 0) ctr->color_start[i / kPerColor] = excl;
+                }
+                run += total;
+            }
+        }
     }
     uint32_t ncol = 0;
     __syncthreads();

@@ -190,9 +190,11 @@ def test_colouring_is_proper_and_order_independent():
 
 
 def test_both_solver_drivers_give_the_same_bits():
-    """contact_solve.h drives the same row arithmetic two ways: Jacobians of all rows made beforehand (the
-    dataflow kernels, which make them while they wait) or row by row on the way (the per-colour kernels and the
-    oracle). Random manifolds, full inertia tensors, with and without a second body: not one bit may differ."""
+    """contact_solve.h drives the same row arithmetic three ways: Jacobians of all rows made beforehand (the
+    dataflow kernels, which make them while they wait), row by row on the way (the per-colour kernels and the oracle),
+    or with lever arms, Jacobians and - in the first sweep - the row masses remade from the contact points and the body
+    positions (`solve_manifold_geo`, the cluster solver's compact rows). Random manifolds, full inertia tensors, with and
+    without a second body, eight sweeps: not one bit may differ between the three."""
     from oracle import binding as ob
     rng = np.random.default_rng(5)
     for trial in range(300):
