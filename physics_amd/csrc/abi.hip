@@ -66,6 +66,7 @@ void poll_snapshots(phys_world* w) {
         w->hint.valid = true;
         w->hint.n_manifolds = c.n_manifolds;
         w->hint.n_colors = c.n_colors;
+        w->hint.n_active = c.n_active;
         // colouring rounds: a full re-colouring and an incremental update need very different counts, and the
         // incremental count fluctuates: remember the full count, and the maximum of the recent incremental ones
         if (w->snap_full[k]) {
@@ -165,7 +166,7 @@ int32_t phys_destroy(phys_world* w) {
     DevBuf<uint32_t>* ub[] = {&w->shape, &w->global_id, &w->cg_status, &w->bucket_of, &w->bucket_count,
                               &w->bucket_start, &w->bucket_cursor, &w->sorted_ids, &w->slot_ids, &w->grid_ovf, &w->scan_block_sums, &w->pairs,
                               &w->man_a, &w->man_b, &w->man_color, &w->row_hdr, &w->halo_block_counts,
-                              &w->cluster_slot, &w->cluster_body, &w->body_shared, &w->seg_count, &w->seg_start, &w->man_rank,
+                              &w->cluster_slot, &w->cluster_body, &w->body_shared, &w->active_flag, &w->active_rank, &w->seg_count, &w->seg_start, &w->man_rank,
                               &w->row_src, &w->cross_pairs, &w->color_block_hist, &w->cg_cols};
     for (auto* b : ub) b->free();
     w->man_prio.free(); w->color_state.free(); w->bucket_count.free(); w->step_zero.free();

@@ -33,6 +33,7 @@ namespace phys {
 // tensors, two otherwise. Measured on C5, same bits: 1 per CU 3.48 ms, 2 per CU 2.70, 3 per CU 2.20
 constexpr int kClusterPerCuDiag = 3, kClusterPerCuFull = 2;
 constexpr size_t kClusterLdsPerCu = 160 * 1024;
+constexpr size_t kClusterSlotBytesDecl = 64;  // == kClusterSlotBytes below
 size_t cluster_lds_bytes(uint32_t slots);
 
 // per-row side info packed into row_n.w (as bits): slot (16) | mode (2) per side
@@ -54,9 +55,11 @@ int32_t cluster_assign(phys_world* w, const float* pos /* host, 3 * n_owned */) 
     w->cluster_count = 0;
     const uint64_t n = w->n, n_owned = w->n_owned;
     static const bool off = getenv("PHYS_DEBUG_NO_CLUSTER") != nullptr;
+    w->cluster_dynamic = false;
     if (off || n_owned < kClusterMinBodies || !w->flow_vel.p) return PHYS_OK;
     int cus = 0;
     PHYS_HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, w->device));
+    w->cluster_cus = cus;
     // one workgroup per cluster, several per CU (their phases interleave: one waits for its rows while the others
     // solve); an eighth of the chip to spare: EVERY workgroup must be resident (the kernel's occupancy bound admits
     // kClusterPerCu* of them per CU; a workgroup that found no room would be waited for until the time-out)
@@ -64,16 +67,41 @@ int32_t cluster_assign(phys_world* w, const float* pos /* host, 3 * n_owned */) 
     const int per_cu_max = w->all_diag_inertia ? kClusterPerCuDiag : kClusterPerCuFull;
     int per_cu = per_cu_env ? std::min(per_cu_max, std::max(1, atoi(per_cu_env))) : per_cu_max;
     static const int spare_div = getenv("PHYS_DEBUG_CLUSTER_SPARE") ? atoi(getenv("PHYS_DEBUG_CLUSTER_SPARE")) : 8;
+    // PHYS_DEBUG_CLUSTER_DYNAMIC: dynamic clusters even where the static ones fit; PHYS_DEBUG_CLUSTER_CAP=<bodies>: fewer
+    // homes than the LDS would hold, so that some bodies stay homeless (tests of exactly that; same bits)
+    static const bool force_dynamic = getenv("PHYS_DEBUG_CLUSTER_DYNAMIC") != nullptr;
+    static const uint64_t cap_env = getenv("PHYS_DEBUG_CLUSTER_CAP") ? strtoull(getenv("PHYS_DEBUG_CLUSTER_CAP"), nullptr, 10) : 0;
+    w->cluster_cap_limit = cap_env;
     uint32_t slots = 0;
+    bool fits = !force_dynamic;
     // ... and the LDS of a CU must hold all of its workgroups' bodies (64 B per slot + the segment table, in 1 KiB
     // allocation units), or the grid would not be resident: fewer, larger clusters per CU until it does
-    for (;; --per_cu) {
+    for (; fits; --per_cu) {
         const uint32_t max_clusters = (uint32_t)std::max(8, per_cu * (cus - (spare_div ? cus / spare_div : 0)));
         slots = (uint32_t)((n_owned + max_clusters - 1) / max_clusters);
         slots = (slots + 63u) / 64u * 64u;
         const size_t per_wg = (cluster_lds_bytes(slots) + 1023) / 1024 * 1024;
         if (per_wg * (size_t)per_cu <= kClusterLdsPerCu && slots <= kClusterMaxSlots) break;
-        if (per_cu == 1) return PHYS_OK;  // the bodies would not fit the CU's LDS: per-colour launches
+        if (per_cu == 1) fits = false;  // the owned bodies do not fit the chip's LDS
+    }
+    if (!fits) {
+        // DYNAMIC clusters: homes are dealt out every update, to the bodies that have a manifold in it, in the broad
+        // phase's bucket order (launch_cluster_sort); their number and size follow the count of such bodies
+        // (cluster_plan_dynamic). Needs the sorted grid of the broad phase (n > 32768: always the case here).
+        const uint32_t clusters_max = (uint32_t)std::max(8, per_cu_max * (cus - (spare_div ? cus / spare_div : 0)));
+        const size_t homes_max = (size_t)cus * (kClusterLdsPerCu / kClusterSlotBytesDecl) + 64;
+        PHYS_HIP_TRY(w->cluster_slot.resize(n));
+        PHYS_HIP_TRY(w->cluster_body.resize(homes_max));
+        PHYS_HIP_TRY(w->body_shared.resize(2 * n));
+        PHYS_HIP_TRY(w->seg_count.resize((size_t)clusters_max * PHYS_MAX_COLORS + 4));
+        PHYS_HIP_TRY(w->seg_start.resize((size_t)clusters_max * PHYS_MAX_COLORS + 4));
+        PHYS_HIP_TRY(w->man_rank.resize(w->max_manifolds));
+        PHYS_HIP_TRY(w->active_flag.resize(n + 4));
+        PHYS_HIP_TRY(w->active_rank.resize(n + 4));
+        w->cluster_dynamic = true;
+        w->cluster_count = 0;
+        w->cluster_slots = 0;
+        return PHYS_OK;
     }
     const uint32_t clusters = (uint32_t)((n_owned + slots - 1) / slots);
     // isotropic Morton key over the bounding box of the owned bodies. Ghost bodies (sharded worlds) get no home in
@@ -115,10 +143,74 @@ int32_t cluster_assign(phys_world* w, const float* pos /* host, 3 * n_owned */) 
     return PHYS_OK;
 }
 
-// ---- per step: rows sorted by (cluster of body A, colour); bodies touched by a row of another cluster ----------
+// ---- dynamic clusters: plan (host, from the lagged count of active bodies) and assignment (device, this update) ----
+bool cluster_plan_dynamic(phys_world* w) {
+    if (!w->cluster_dynamic) return false;
+    // the count of the last cluster step; before the first one: no more bodies than twice the manifolds can be active
+    uint64_t active = w->hint.n_active;
+    if (active == 0) active = std::min<uint64_t>(w->n_owned, 2ull * w->hint.n_manifolds);
+    if (active == 0) return false;
+    static const int spare_div = getenv("PHYS_DEBUG_CLUSTER_SPARE") ? atoi(getenv("PHYS_DEBUG_CLUSTER_SPARE")) : 8;
+    static const char* per_cu_env = getenv("PHYS_DEBUG_CLUSTERS_PER_CU");
+    const int per_cu_max = w->all_diag_inertia ? kClusterPerCuDiag : kClusterPerCuFull;
+    int per_cu = per_cu_env ? std::min(per_cu_max, std::max(1, atoi(per_cu_env))) : per_cu_max;
+    const int cus = w->cluster_cus;
+    // homes for a quarter more bodies than the last known count; what does not get one is served as "another cluster's
+    // body" (slower, never wrong), so this is a matter of speed only
+    uint64_t want = active + active / 4;
+    if (w->cluster_cap_limit && want > w->cluster_cap_limit) want = w->cluster_cap_limit;
+    for (;; --per_cu) {
+        const uint32_t clusters = (uint32_t)std::max(8, per_cu * (cus - (spare_div ? cus / spare_div : 0)));
+        uint32_t slots = (uint32_t)((want + clusters - 1) / clusters);
+        slots = std::max(64u, (slots + 63u) / 64u * 64u);
+        const size_t per_wg = (cluster_lds_bytes(slots) + 1023) / 1024 * 1024;
+        const bool ok = per_wg * (size_t)per_cu <= kClusterLdsPerCu && slots <= kClusterMaxSlots;
+        if (ok || per_cu == 1) {
+            if (!ok) slots = kClusterMaxSlots / 64u * 64u;  // one workgroup per CU, as many homes as its LDS holds
+            w->cluster_count = clusters;
+            w->cluster_slots = slots;
+            return true;
+        }
+    }
+}
+
+// position of an owned body in the broad phase's bucket order (what k_scatter computed), or ~0
+__device__ __forceinline__ uint32_t bucket_order(uint32_t i, const uint32_t* __restrict__ bucket_of, const uint32_t* __restrict__ rank,
+                                                 const uint32_t* __restrict__ bucket_start) {
+    const uint32_t bk = bucket_of[i];
+    return bk == 0xFFFFFFFFu ? 0xFFFFFFFFu : bucket_start[bk] + rank[i];
+}
+__global__ __launch_bounds__(256) void k_active_flags(uint32_t n_owned, const unsigned long long* __restrict__ used,
+                                                      const uint32_t* __restrict__ bucket_of, const uint32_t* __restrict__ rank,
+                                                      const uint32_t* __restrict__ bucket_start, uint32_t* __restrict__ flag) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_owned || used[i] == 0ull) return;  // flag[] was zeroed
+    const uint32_t s = bucket_order(i, bucket_of, rank, bucket_start);
+    if (s != 0xFFFFFFFFu) flag[s] = 1u;
+}
+__global__ __launch_bounds__(256) void k_cluster_homes(uint32_t n, uint32_t n_owned, const unsigned long long* __restrict__ used,
+                                                       const uint32_t* __restrict__ bucket_of, const uint32_t* __restrict__ rank,
+                                                       const uint32_t* __restrict__ bucket_start, const uint32_t* __restrict__ active_rank,
+                                                       uint32_t total_at, uint32_t homes, uint32_t* __restrict__ cluster_slot,
+                                                       uint32_t* __restrict__ cluster_body, StepCounters* __restrict__ ctr) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) ctr->n_active = active_rank[total_at];  // the scan's grand total
+    if (i >= n) return;
+    uint32_t home = kNoHome;
+    if (i < n_owned && used[i] != 0ull) {
+        const uint32_t s = bucket_order(i, bucket_of, rank, bucket_start);
+        if (s != 0xFFFFFFFFu) {
+            const uint32_t r = active_rank[s];
+            if (r < homes) { home = r; cluster_body[r] = i; }
+        }
+    }
+    cluster_slot[i] = home;
+}
+
+// ---- per step: rows sorted by (owner cluster, colour); bodies touched by a row of another cluster ----------
 __global__ __launch_bounds__(256) void k_cluster_keys(uint64_t max_manifolds, const uint32_t* __restrict__ man_a,
                                                       const uint32_t* __restrict__ man_b, const uint32_t* __restrict__ man_color,
-                                                      const uint32_t* __restrict__ cluster_slot, uint32_t slots,
+                                                      const uint32_t* __restrict__ cluster_slot, uint32_t slots, uint32_t clusters,
                                                       uint32_t* __restrict__ seg_count, uint32_t* __restrict__ man_rank,
                                                       uint32_t* __restrict__ body_shared, const StepCounters* __restrict__ ctr) {
     const uint32_t raw = ctr->n_manifolds;
@@ -126,19 +218,21 @@ __global__ __launch_bounds__(256) void k_cluster_keys(uint64_t max_manifolds, co
     for (uint32_t m = blockIdx.x * blockDim.x + threadIdx.x; m < M; m += gridDim.x * blockDim.x) {
         const uint32_t a = man_a[m], b = man_b[m], c = man_color[m];
         if (c >= (uint32_t)PHYS_MAX_COLORS) { man_rank[m] = 0xFFFFFFFFu; continue; }
-        const uint32_t ca = cluster_slot[a] / slots;
+        const uint32_t ha = cluster_home(cluster_slot, a, slots);
+        const uint32_t hb = b == PHYS_GROUND_ID ? kNoHome : cluster_home(cluster_slot, b, slots);
+        const uint32_t owner = cluster_row_owner(a, ha, hb, clusters);
         // arrival order inside a (cluster, colour) segment: nothing depends on it (rows of one colour share no body)
-        man_rank[m] = atomicAdd(&seg_count[ca * PHYS_MAX_COLORS + c], 1u);
-        // a row is owned by the cluster of its body A, so the only updates a body ever receives from ANOTHER workgroup are
-        // those of cross rows in which it is body B: that body is `shared`, and the colours of those rows are its
-        // remote colours (two 32-bit halves of a 64-bit mask)
-        if (b != PHYS_GROUND_ID && cluster_slot[b] / slots != ca) atomicOr(&body_shared[2 * (size_t)b + (c >> 5)], 1u << (c & 31u));
+        man_rank[m] = atomicAdd(&seg_count[owner * PHYS_MAX_COLORS + c], 1u);
+        // a body with a home receives updates from ANOTHER workgroup exactly in the rows that its home does not own:
+        // that body is `shared`, and the colours of those rows are its remote colours (two halves of a 64-bit mask).
+        // (A's home owns the row whenever A has one.)
+        if (hb != kNoHome && hb != owner) atomicOr(&body_shared[2 * (size_t)b + (c >> 5)], 1u << (c & 31u));
     }
 }
 
 __global__ __launch_bounds__(256) void k_cluster_place(uint64_t max_manifolds, const uint32_t* __restrict__ man_a,
-                                                       const uint32_t* __restrict__ man_color,
-                                                       const uint32_t* __restrict__ cluster_slot, uint32_t slots,
+                                                       const uint32_t* __restrict__ man_b, const uint32_t* __restrict__ man_color,
+                                                       const uint32_t* __restrict__ cluster_slot, uint32_t slots, uint32_t clusters,
                                                        const uint32_t* __restrict__ seg_start, const uint32_t* __restrict__ man_rank,
                                                        uint32_t* __restrict__ row_src, const StepCounters* __restrict__ ctr) {
     const uint32_t raw = ctr->n_manifolds;
@@ -146,7 +240,10 @@ __global__ __launch_bounds__(256) void k_cluster_place(uint64_t max_manifolds, c
     for (uint32_t m = blockIdx.x * blockDim.x + threadIdx.x; m < M; m += gridDim.x * blockDim.x) {
         const uint32_t r = man_rank[m];
         if (r == 0xFFFFFFFFu) continue;
-        row_src[seg_start[(cluster_slot[man_a[m]] / slots) * PHYS_MAX_COLORS + man_color[m]] + r] = m;
+        const uint32_t a = man_a[m], b = man_b[m];
+        const uint32_t ha = cluster_home(cluster_slot, a, slots);
+        const uint32_t hb = (ha != kNoHome || b == PHYS_GROUND_ID) ? kNoHome : cluster_home(cluster_slot, b, slots);
+        row_src[seg_start[cluster_row_owner(a, ha, hb, clusters) * PHYS_MAX_COLORS + man_color[m]] + r] = m;
     }
 }
 
@@ -157,13 +254,27 @@ void launch_cluster_sort(phys_world* w, unsigned blocks) {
     hipStream_t s = w->stream;
     const uint32_t bins = w->cluster_count * PHYS_MAX_COLORS;  // a multiple of 64
     PHYS_PROF(w, PHYS_STAGE_ROWS);
+    if (w->cluster_dynamic) {
+        // homes of this update: the bodies that have a manifold in it (used mask != 0, complete after the colouring), in the
+        // bucket order of this update's broad phase - neighbours in space are neighbours in that order
+        const uint32_t n = (uint32_t)w->n, homes = w->cluster_count * w->cluster_slots;
+        const dim3 g((n + 255) / 256), b(256);
+        (void)hipMemsetAsync(w->active_flag.p, 0, ((size_t)n + 4) * 4, s);
+        (void)hipMemsetAsync(w->cluster_body.p, 0xFF, (size_t)homes * 4, s);
+        hipLaunchKernelGGL(k_active_flags, g, b, 0, s, (uint32_t)w->n_owned, w->color_state.p, w->bucket_of.p, w->bucket_cursor.p,
+                           w->bucket_start.p, w->active_flag.p);
+        const uint32_t n4 = (n + 3u) & ~3u;  // the scans want a multiple of four; the total lands behind the last entry
+        launch_exclusive_scan(w, w->active_flag.p, n4, w->active_rank.p);
+        hipLaunchKernelGGL(k_cluster_homes, g, b, 0, s, n, (uint32_t)w->n_owned, w->color_state.p, w->bucket_of.p, w->bucket_cursor.p,
+                           w->bucket_start.p, w->active_rank.p, n4, homes, w->cluster_slot.p, w->cluster_body.p, w->counters.p);
+    }
     (void)hipMemsetAsync(w->seg_count.p, 0, (size_t)bins * 4, s);
     (void)hipMemsetAsync(w->body_shared.p, 0, (size_t)w->n * 8, s);
     hipLaunchKernelGGL(k_cluster_keys, dim3(blocks), dim3(256), 0, s, w->max_manifolds, w->man_a.p, w->man_b.p, w->man_color.p,
-                       w->cluster_slot.p, w->cluster_slots, w->seg_count.p, w->man_rank.p, w->body_shared.p, w->counters.p);
+                       w->cluster_slot.p, w->cluster_slots, w->cluster_count, w->seg_count.p, w->man_rank.p, w->body_shared.p, w->counters.p);
     launch_exclusive_scan(w, w->seg_count.p, bins, w->seg_start.p);
-    hipLaunchKernelGGL(k_cluster_place, dim3(blocks), dim3(256), 0, s, w->max_manifolds, w->man_a.p, w->man_color.p,
-                       w->cluster_slot.p, w->cluster_slots, w->seg_start.p, w->man_rank.p, w->row_src.p, w->counters.p);
+    hipLaunchKernelGGL(k_cluster_place, dim3(blocks), dim3(256), 0, s, w->max_manifolds, w->man_a.p, w->man_b.p, w->man_color.p,
+                       w->cluster_slot.p, w->cluster_slots, w->cluster_count, w->seg_start.p, w->man_rank.p, w->row_src.p, w->counters.p);
 }
 
 // ---- the solver ----------------------------------------------------------------------------------------------
@@ -300,7 +411,7 @@ __global__ __launch_bounds__(kClusterThreads, DIAG ? kClusterPerCuDiag : kCluste
                 uint32_t modeA = (info >> 14) & 3u, modeB = (info >> 30) & 3u;
                 const uint32_t slotA = info & 0x1FFFu, slotB = (info >> 16) & 0x1FFFu;
                 const bool pubA = (info >> 13) & 1u, pubB = (info >> 29) & 1u;
-                if (ablate & 8u) { modeA = 0u; if (modeB == 1u) modeB = 0u; }  // PHYS_DEBUG_ABLATE (timing only, wrong results)
+                if (ablate & 8u) { if (modeA == 1u) modeA = 0u; if (modeB == 1u) modeB = 0u; }  // PHYS_DEBUG_ABLATE (timing only, wrong results)
                 geo_manifold_t gm;
                 gm.count = (int)h.z;
                 gm.has_b = h.y != PHYS_GROUND_ID;
@@ -329,13 +440,26 @@ __global__ __launch_bounds__(kClusterThreads, DIAG ? kClusterPerCuDiag : kCluste
                 m33 IA, IB;
 #pragma unroll
                 for (int k = 0; k < 9; ++k) { IA.m[k] = 0.0f; IB.m[k] = 0.0f; }
-                {
-                    const float4* sa = s_body + 4 * slotA;  // A is always of this cluster
+                v3 vA0 = v3_make(0.0f, 0.0f, 0.0f);
+                vA = vA0; wA = vA0; xA = vA0; ima = 0.0f;
+                if (modeA == 0u || modeA == 1u) {  // A at home here (always, unless it has no home at all)
+                    const float4* sa = s_body + 4 * slotA;
                     const float4 la = sa[0], lb = sa[1], lc = sa[2];
                     vA = v3_make(la.x, la.y, la.z); wA = v3_make(lb.x, lb.y, lb.z); ima = lb.w;
                     xA = v3_make(lc.x, lc.y, lc.z);
                     if (DIAG) { const float4 li = sa[3]; IA.m[0] = li.x; IA.m[4] = li.y; IA.m[8] = li.z; }
                     if (modeA == 1u) needA = __float_as_uint(la.w) != (etag | tA);  // a remote row made the update before this one
+                } else {
+                    // a body without a home (dynamic clusters beyond their capacity): like a foreign body B, its constants
+                    // came with the row (planes 14, 15) - fetched here, not ahead: the case is rare by construction
+                    const float4 fa = rows.all[(size_t)(kClusterPlaneForeign + 2) * cap + d_row];
+                    xA = v3_make(fa.x, fa.y, fa.z); ima = fa.w;
+                    if (DIAG) {
+                        const float4 fia = rows.all[(size_t)(kClusterPlaneForeign + 3) * cap + d_row];
+                        IA.m[0] = fia.x; IA.m[4] = fia.y; IA.m[8] = fia.z;
+                    }
+                    if (tA == 0u) { const BodyVel A0 = ld_vel(vel, h.x); vA = A0.v; wA = A0.w; }
+                    needA = tA != 0u && !(ablate & 8u);
                 }
                 if (modeB == 0u || modeB == 1u) {
                     const float4* sb = s_body + 4 * slotB;
@@ -387,11 +511,13 @@ __global__ __launch_bounds__(kClusterThreads, DIAG ? kClusterPerCuDiag : kCluste
                 if (!dead) {
                     if (!(ablate & 2u)) solve_manifold_geo(&gm, it == 0u || (ablate & 32u), friction, xA, ima, &IA, xB, imb, &IB, &vA, &wA, &vB, &wB);
                     // ---- write back
-                    s_body[4 * slotA] = make_float4(vA.x, vA.y, vA.z, __uint_as_float(etag | (tA + 1u)));
-                    s_body[4 * slotA + 1] = make_float4(wA.x, wA.y, wA.z, ima);
-                    if (modeA == 1u) {
+                    if (modeA == 0u || modeA == 1u) {
+                        s_body[4 * slotA] = make_float4(vA.x, vA.y, vA.z, __uint_as_float(etag | (tA + 1u)));
+                        s_body[4 * slotA + 1] = make_float4(wA.x, wA.y, wA.z, ima);
+                    }
+                    if (modeA == 1u || modeA == 2u) {
                         if (finalA) { st3(vel + 8 * (size_t)h.x, 0, vA); st3(vel + 8 * (size_t)h.x + 4, 0, wA); }  // the masses stay where they are
-                        else if (pubA) { st_gran(rv, h.x * 32u, vA, etag | (tA + 1u)); st_gran(rv, h.x * 32u + 16u, wA, etag | (tA + 1u)); }
+                        else if (modeA == 2u || pubA) { st_gran(rv, h.x * 32u, vA, etag | (tA + 1u)); st_gran(rv, h.x * 32u + 16u, wA, etag | (tA + 1u)); }
                     }
                     if (modeB == 0u || modeB == 1u) {
                         s_body[4 * slotB] = make_float4(vB.x, vB.y, vB.z, __uint_as_float(etag | (tB + 1u)));

@@ -105,6 +105,21 @@ __device__ __forceinline__ void color_table_insert(const ColorTableJob& job, uin
     }
 }
 
+// Cluster solver: which cluster's workgroup owns a row. A body has a HOME cluster (cluster_slot / slots) or none (ghost
+// bodies of a sharded world; bodies beyond the capacity of a dynamic clustering). A row is owned by the home of its
+// body A, else by the home of its body B, else - both homeless - by a cluster picked from A's id. A side whose body's
+// home is the owner is served from that workgroup's LDS; every other side is "another cluster's body".
+constexpr uint32_t kNoHome = 0xFFFFFFFFu;
+__device__ __forceinline__ uint32_t cluster_home(const uint32_t* __restrict__ cluster_slot, uint32_t body, uint32_t slots) {
+    const uint32_t s = cluster_slot[body];
+    return s == kNoHome ? kNoHome : s / slots;
+}
+__device__ __forceinline__ uint32_t cluster_row_owner(uint32_t a, uint32_t home_a, uint32_t home_b, uint32_t clusters) {
+    if (home_a != kNoHome) return home_a;
+    if (home_b != kNoHome) return home_b;
+    return ((a * 2654435761u) >> 7) % clusters;
+}
+
 // integrate.hip
 void launch_step_full(phys_world* w, float dt, bool gravity);
 void launch_step_velocity_aabb(phys_world* w, float dt, bool gravity, bool zero_step);  // zero_step: also zero the per-step state
@@ -143,6 +158,7 @@ int32_t halo_pairs(phys_world* w, const void* dev_remote, uint64_t n_remote, uin
 int32_t cluster_assign(phys_world* w, const float* host_pos);
 void launch_cluster_sort(phys_world* w, unsigned blocks);
 void launch_exclusive_scan(phys_world* w, const uint32_t* in, uint32_t count, uint32_t* out);  // broadphase.hip; count % 4 == 0
+bool cluster_plan_dynamic(phys_world* w);  // cluster.hip: clusters / slots of this update from the hint (dynamic clusters)
 void launch_solve_cluster(phys_world* w, void* row_all, uint64_t cap, float friction, const float* inertia, uint32_t stride,
                           bool diag, long long timeout_ticks);
 

@@ -755,10 +755,12 @@ void launch_coloring(phys_world* w) {
     // worth it where contacts are dense (C5: 11 rows per body): velocities stay in LDS for many rows each. Sparse piles
     // (the 1M-cube scene: 0.4-0.5 rows per body, contacts in the bottom layers only) leave most clusters idle and a few
     // overloaded - they keep the dataflow / per-colour kernels, which spread rows evenly over the chip
-    const bool dense = cluster_min_env || 2ull * w->hint.n_manifolds >= 3ull * w->n_owned;
-    w->cluster_step = w->cluster_count > 0 && w->hint.valid && !small && dense && w->hint.n_manifolds >= cluster_min &&
-                      !(w->cfg.flags & PHYS_FLAG_SOLVER_PER_COLOR) && w->cfg.solver_iterations > 0 &&
-                      w->cfg.solver_iterations < 1000 && w->hint.n_colors > 0;
+    // (dynamic clusters hold only the bodies that have manifolds: nothing idles, the row count alone decides)
+    const bool dense = cluster_min_env || w->cluster_dynamic || 2ull * w->hint.n_manifolds >= 3ull * w->n_owned;
+    w->cluster_step = (w->cluster_count > 0 || w->cluster_dynamic) && w->hint.valid && !small && dense &&
+                      w->hint.n_manifolds >= cluster_min && !(w->cfg.flags & PHYS_FLAG_SOLVER_PER_COLOR) &&
+                      w->cfg.solver_iterations > 0 && w->cfg.solver_iterations < 1000 && w->hint.n_colors > 0;
+    if (w->cluster_step && w->cluster_dynamic) w->cluster_step = cluster_plan_dynamic(w);  // clusters and slots of this update
     if (small) {
         // one workgroup does the whole stage, snapshot of the counters included
         StepCounters* slot = snapshot_acquire(w);
@@ -823,6 +825,7 @@ void launch_coloring(phys_world* w) {
             w->hint.valid = true;
             w->hint.n_manifolds = c.n_manifolds;
             w->hint.n_colors = c.n_colors;
+            w->hint.n_active = c.n_active;
             if (full) w->hint.full_rounds = c.color_rounds; else w->hint.color_rounds = c.color_rounds;
             for (int q = 0; q < kMaxColors; ++q) w->hint.color_count[q] = c.color_count[q];
         }

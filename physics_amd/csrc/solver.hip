@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void k_rows_build(const StepCounters* __restri
                                                     int flow /* 1: k_solve_flow runs this step (tickets, no zeroed impulses) */,
                                                     ColorTableJob table, const uint32_t* __restrict__ cluster_slot,
                                                     const uint32_t* __restrict__ body_shared,
-                                                    uint32_t cluster_slots /* 0: not a cluster-solver step */) {
+                                                    uint32_t cluster_slots /* 0: not a cluster-solver step */, uint32_t cluster_count) {
     if (ctr->overflow) return;  // never solve a truncated set; phys_sync / phys_get_stats report it
     const uint32_t M = ctr->n_manifolds;
     const uint64_t cap = rows.cap;
@@ -114,37 +114,24 @@ __global__ __launch_bounds__(256) void k_rows_build(const StepCounters* __restri
             // publish: the body's NEXT update in solve order (next colour in use at the body, cyclically) belongs to a
             // remote row, so this update must be written to the granules for it
             const unsigned long long bitc = 1ull << man_color[m];
-            const uint32_t sa = cluster_slot[a];
-            const uint32_t ca = sa / cluster_slots;
-            {
-                const unsigned long long rem = ((unsigned long long)body_shared[2 * (size_t)a + 1] << 32) | body_shared[2 * (size_t)a];
+            const uint32_t ha = cluster_home(cluster_slot, a, cluster_slots);
+            const uint32_t hb = has_b ? cluster_home(cluster_slot, b, cluster_slots) : kNoHome;
+            const uint32_t owner = cluster_row_owner(a, ha, hb, cluster_count);
+            // one side: {slot | publish | mode} of body x whose home is `hx`
+            auto side = [&](uint32_t x, uint32_t hx) -> uint32_t {
+                if (hx != owner) return 2u << 14;  // homeless, or at home elsewhere
+                const unsigned long long rem = ((unsigned long long)body_shared[2 * (size_t)x + 1] << 32) | body_shared[2 * (size_t)x];
                 uint32_t pub = 0;
                 if (rem) {
-                    const unsigned long long ua = used[a];
-                    const unsigned long long above = ua & ~(bitc | (bitc - 1ull));
-                    const unsigned long long next = above ? (above & (~above + 1ull)) : (ua & (~ua + 1ull));  // lowest colour above, else the first
+                    const unsigned long long ux = used[x];
+                    const unsigned long long above = ux & ~(bitc | (bitc - 1ull));
+                    const unsigned long long next = above ? (above & (~above + 1ull)) : (ux & (~ux + 1ull));  // lowest colour above, else the first
                     pub = (rem & next) ? 1u : 0u;
                 }
-                info = (sa - ca * cluster_slots) | (pub << 13) | ((rem ? 1u : 0u) << 14);
-            }
-            uint32_t ib = 3u << 14;
-            if (has_b) {
-                const uint32_t sb = cluster_slot[b];
-                const uint32_t cb = sb / cluster_slots;
-                if (cb == ca) {
-                    const unsigned long long rem = ((unsigned long long)body_shared[2 * (size_t)b + 1] << 32) | body_shared[2 * (size_t)b];
-                    uint32_t pub = 0;
-                    if (rem) {
-                        const unsigned long long ub = used[b];
-                        const unsigned long long above = ub & ~(bitc | (bitc - 1ull));
-                        const unsigned long long next = above ? (above & (~above + 1ull)) : (ub & (~ub + 1ull));
-                        pub = (rem & next) ? 1u : 0u;
-                    }
-                    ib = (sb - cb * cluster_slots) | (pub << 13) | ((rem ? 1u : 0u) << 14);
-                } else {
-                    ib = 2u << 14;
-                }
-            }
+                return (cluster_slot[x] - hx * cluster_slots) | (pub << 13) | ((rem ? 1u : 0u) << 14);
+            };
+            info = side(a, ha);
+            const uint32_t ib = has_b ? side(b, hb) : (3u << 14);
             info |= ib << 16;
         }
         rows.n[d] = make_float4(g.normal.x, g.normal.y, g.normal.z, __uint_as_float(info));
@@ -161,6 +148,12 @@ __global__ __launch_bounds__(256) void k_rows_build(const StepCounters* __restri
                 const v3 xb = ld3(pos, b);
                 rows.all[(size_t)12 * cap + d] = make_float4(xb.x, xb.y, xb.z, vel[8 * (size_t)b + 3]);
                 if (DIAG) rows.all[(size_t)13 * cap + d] = reinterpret_cast<const float4*>(inv_inertia)[b * inertia_stride];
+            }
+            if (((info >> 14) & 3u) == 2u) {
+                // body A has no home (dynamic clusters beyond their capacity): the same for A in planes 14, 15
+                const v3 xa = ld3(pos, a);
+                rows.all[(size_t)14 * cap + d] = make_float4(xa.x, xa.y, xa.z, vel[8 * (size_t)a + 3]);
+                if (DIAG) rows.all[(size_t)15 * cap + d] = reinterpret_cast<const float4*>(inv_inertia)[a * inertia_stride];
             }
             continue;
         }
@@ -1048,12 +1041,12 @@ void launch_solver(phys_world* w, float dt) {
           hipLaunchKernelGGL(k_rows_build<true>, grid_for_count(m_hint), tb, 0, s, w->counters.p, rows, sp, w->row_src.p, w->man_geo.p,
                              w->pos.p, w->vel.p, inertia, stride, w->man_color.p,
                              w->color_state.p, flow ? (stall ? 2 : 1) : 0, table, w->cluster_slot.p, w->body_shared.p,
-                             w->cluster_step ? w->cluster_slots : 0u);
+                             w->cluster_step ? w->cluster_slots : 0u, w->cluster_count);
       else
           hipLaunchKernelGGL(k_rows_build<false>, grid_for_count(m_hint), tb, 0, s, w->counters.p, rows, sp, w->row_src.p, w->man_geo.p,
                              w->pos.p, w->vel.p, inertia, stride, w->man_color.p,
                              w->color_state.p, flow ? (stall ? 2 : 1) : 0, table, w->cluster_slot.p, w->body_shared.p,
-                             w->cluster_step ? w->cluster_slots : 0u); }
+                             w->cluster_step ? w->cluster_slots : 0u, w->cluster_count); }
     if (flow) {
         if (++w->flow_epoch > 0xFFFFu) {  // tags would repeat: forget every old one
             (void)hipMemsetAsync(w->flow_vel.p, 0, 8 * w->n * sizeof(float), s);

@@ -71,6 +71,7 @@ struct StepCounters {
     uint32_t n_ground_manifolds;
     uint32_t flow_ticket;    // k_solve_flow: next (iteration, row chunk) item to hand to a workgroup
     uint32_t n_grid_ovf;     // slot grid: bodies that found their bucket's four slots taken
+    uint32_t n_active;       // owned bodies with at least one manifold in this update (dynamic clusters, cluster.hip)
     uint32_t unc_count[3];   // colouring rounds: length of the list of uncoloured manifolds read / written / cleared (rotating)
     uint32_t color_count[kMaxColors];  // manifolds per colour
     uint32_t color_start[kMaxColors + 1];
@@ -139,6 +140,7 @@ struct ProfScope {
 struct StepHint {
     bool valid = false;
     uint32_t n_manifolds = 0, n_colors = 0;
+    uint32_t n_active = 0;         // owned bodies with a manifold (0 = unknown)
     uint32_t color_rounds = 0;     // max over the recent INCREMENTAL updates
     uint32_t full_rounds = 0;      // rounds of the last full re-colouring (0 = unknown)
     uint32_t recent_rounds[8] = {};
@@ -240,7 +242,11 @@ struct phys_world {
     // ready flag)
     phys::DevBuf<float> flow_vel;    // 8 per body: {v.xyz, tag} {w.xyz, tag}; null = per-colour launches only
     // cluster solver (cluster.hip): spatial clusters fixed at phys_set_bodies, rows sorted by (cluster, colour) per step
-    uint32_t cluster_count = 0, cluster_slots = 0;  // 0 clusters: not available for this scene
+    uint32_t cluster_count = 0, cluster_slots = 0;  // 0 clusters: not available for this scene (dynamic: set per update)
+    bool cluster_dynamic = false;           // clusters are remade every update from the bodies that have manifolds (cluster.hip)
+    int cluster_cus = 0;                    // CUs of the device (dynamic planning)
+    uint64_t cluster_cap_limit = 0;         // PHYS_DEBUG_CLUSTER_CAP: fewer homes than the LDS would hold (tests)
+    phys::DevBuf<uint32_t> active_flag, active_rank;  // n + 4 each: flag / exclusive rank in the broad phase's bucket order
     bool cluster_step = false;                      // this update's rows are in (cluster, colour) order
     phys::DevBuf<uint32_t> cluster_slot;   // body -> cluster * slots + slot
     phys::DevBuf<uint32_t> cluster_body;   // cluster * slots + slot -> body (0xFFFFFFFF: empty)

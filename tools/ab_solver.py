@@ -32,6 +32,8 @@ VARIANTS = {
     "cl_remass": {"PHYS_DEBUG_ABLATE": "32"},   # same bits: row masses remade in every iteration
     "cl_norot_remass": {"PHYS_DEBUG_ABLATE": "48"},
     "cluster2": {"PHYS_DEBUG_CLUSTERS_PER_CU": "2"},
+    "dyn": {"PHYS_DEBUG_CLUSTER_DYNAMIC": "1"},                                     # clusters remade every update
+    "dyn_cap": {"PHYS_DEBUG_CLUSTER_DYNAMIC": "1", "PHYS_DEBUG_CLUSTER_CAP": "60000"},  # ... with homes for 60k bodies only
     "flow_pipe": {"PHYS_DEBUG_FLOW_MAX": "100000000", "PHYS_DEBUG_NO_CLUSTER": "1", "PHYS_DEBUG_FLOW_PIPELINE": "1"},
     "flow_nopipe": {"PHYS_DEBUG_FLOW_MAX": "100000000", "PHYS_DEBUG_NO_CLUSTER": "1", "PHYS_DEBUG_FLOW_PIPELINE": "0"},
     "np128": {"PHYS_DEBUG_NP_THREADS": "128"},
