@@ -436,3 +436,23 @@ def test_cluster_solver_bit_exact_against_the_oracle_on_a_33k_tower():
     sw, so = w.get_stats(), o.get_stats()
     assert (sw.n_pairs, sw.n_manifolds, sw.n_contacts, sw.n_colors) == (so.n_pairs, so.n_manifolds, so.n_contacts, so.n_colors)
     assert sw.n_manifolds > 300_000
+
+
+@pytest.mark.parametrize("cap", ["", "9000"])
+def test_dynamic_clusters_equal_the_per_colour_kernels(cap):
+    """Scenes whose bodies outnumber the chip's LDS (the 1M-cube drop) get DYNAMIC clusters: homes are dealt out every
+    update to the bodies that have a manifold in it, in the broad phase's bucket order; a row belongs to the home of its
+    body A, else of B; a body without a home (more active bodies than homes) is served as "another cluster's body" on
+    whichever side it stands. Forced here on a 33k tower in a fresh process (the library reads the switches once), with
+    homes for everybody and with homes for 9000 of the 33 280 bodies: the same bits as the per-colour kernels."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PHYS_DEBUG_CLUSTER_DYNAMIC="1")
+    if cap:
+        env["PHYS_DEBUG_CLUSTER_CAP"] = cap
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "dynamic_cluster_probe.py")], cwd=root, env=env,
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "identical cluster_ran True per_colour_ran_cluster False" in out.stdout, out.stdout + out.stderr
