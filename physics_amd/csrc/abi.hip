@@ -66,7 +66,7 @@ void poll_snapshots(phys_world* w) {
         w->hint.valid = true;
         w->hint.n_manifolds = c.n_manifolds;
         w->hint.n_colors = c.n_colors;
-        w->hint.n_active = c.n_active;
+        if (c.n_active) w->hint.n_active = c.n_active;  // counted only in the updates that deal out the dynamic homes
         // colouring rounds: a full re-colouring and an incremental update need very different counts, and the
         // incremental count fluctuates: remember the full count, and the maximum of the recent incremental ones
         if (w->snap_full[k]) {

@@ -23,6 +23,7 @@
 // bit-identical to the other solver paths.
 #include <algorithm>
 #include <cstdlib>
+#include <mutex>
 #include <vector>
 
 #include "kernels.hpp"
@@ -56,6 +57,7 @@ int32_t cluster_assign(phys_world* w, const float* pos /* host, 3 * n_owned */) 
     const uint64_t n = w->n, n_owned = w->n_owned;
     static const bool off = getenv("PHYS_DEBUG_NO_CLUSTER") != nullptr;
     w->cluster_dynamic = false;
+    w->cluster_homes_valid = false;
     if (off || n_owned < kClusterMinBodies || !w->flow_vel.p) return PHYS_OK;
     int cus = 0;
     PHYS_HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, w->device));
@@ -146,7 +148,11 @@ int32_t cluster_assign(phys_world* w, const float* pos /* host, 3 * n_owned */) 
 // ---- dynamic clusters: plan (host, from the lagged count of active bodies) and assignment (device, this update) ----
 bool cluster_plan_dynamic(phys_world* w) {
     if (!w->cluster_dynamic) return false;
-    // the count of the last cluster step; before the first one: no more bodies than twice the manifolds can be active
+    // the homes stay for kClusterDynamicPeriod cluster steps (a pile changes slowly; the deal is three passes over all
+    // bodies); the plan is only made when they are dealt out again
+    if (w->cluster_homes_valid && w->cluster_age < kClusterDynamicPeriod) return true;
+    w->cluster_homes_valid = false;
+    // the count of the last deal; before the first one: no more bodies than twice the manifolds can be active
     uint64_t active = w->hint.n_active;
     if (active == 0) active = std::min<uint64_t>(w->n_owned, 2ull * w->hint.n_manifolds);
     if (active == 0) return false;
@@ -254,8 +260,11 @@ void launch_cluster_sort(phys_world* w, unsigned blocks) {
     hipStream_t s = w->stream;
     const uint32_t bins = w->cluster_count * PHYS_MAX_COLORS;  // a multiple of 64
     PHYS_PROF(w, PHYS_STAGE_ROWS);
-    if (w->cluster_dynamic) {
-        // homes of this update: the bodies that have a manifold in it (used mask != 0, complete after the colouring), in the
+    if (w->cluster_dynamic && w->cluster_homes_valid) ++w->cluster_age;
+    if (w->cluster_dynamic && !w->cluster_homes_valid) {
+        w->cluster_homes_valid = true;
+        w->cluster_age = 0;
+        // homes from this update on: the bodies that have a manifold in it (used mask != 0, complete after the colouring), in the
         // bucket order of this update's broad phase - neighbours in space are neighbours in that order
         const uint32_t n = (uint32_t)w->n, homes = w->cluster_count * w->cluster_slots;
         const dim3 g((n + 255) / 256), b(256);
@@ -575,6 +584,17 @@ void launch_solve_cluster(phys_world* w, void* row_all, uint64_t cap, float fric
         attr_set[diag ? 1 : 0] = true;
     }
     const dim3 g(w->cluster_count), b(kClusterThreads);
+    // Every workgroup of this launch must be resident at once, which the grid size guarantees only if no OTHER launch of
+    // this kernel shares the device: two worlds of one process (two streams) would each get part of the CUs and wait for
+    // the rest until the time-out. Launches of this kernel are therefore chained per device, across worlds, through one
+    // event. (Another PROCESS on the same GPU is beyond this: there the bounded spin ends in PHYS_ERR_HIP.)
+    static std::mutex chain_lock;
+    static hipEvent_t chain_event[64] = {};
+    std::lock_guard<std::mutex> hold(chain_lock);
+    hipEvent_t& ev = chain_event[w->device & 63];
+    if (ev) (void)hipStreamWaitEvent(w->stream, ev, 0);
+    else (void)hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+    struct Record { hipEvent_t e; hipStream_t s; ~Record() { if (e) (void)hipEventRecord(e, s); } } record{ev, w->stream};
     if (diag)
         hipLaunchKernelGGL(k_solve_cluster<true>, g, b, lds, w->stream, w->counters.p, w->cfg.solver_iterations, w->flow_epoch, rows, friction,
                            inertia, stride, w->vel.p, w->pos.p, w->flow_vel.p, (uint32_t)w->n, w->cluster_body.p, w->body_shared.p,

@@ -760,7 +760,7 @@ void launch_coloring(phys_world* w) {
     w->cluster_step = (w->cluster_count > 0 || w->cluster_dynamic) && w->hint.valid && !small && dense &&
                       w->hint.n_manifolds >= cluster_min && !(w->cfg.flags & PHYS_FLAG_SOLVER_PER_COLOR) &&
                       w->cfg.solver_iterations > 0 && w->cfg.solver_iterations < 1000 && w->hint.n_colors > 0;
-    if (w->cluster_step && w->cluster_dynamic) w->cluster_step = cluster_plan_dynamic(w);  // clusters and slots of this update
+    if (w->cluster_step && w->cluster_dynamic) w->cluster_step = cluster_plan_dynamic(w);  // clusters and slots (every few updates)
     if (small) {
         // one workgroup does the whole stage, snapshot of the counters included
         StepCounters* slot = snapshot_acquire(w);
@@ -825,7 +825,7 @@ void launch_coloring(phys_world* w) {
             w->hint.valid = true;
             w->hint.n_manifolds = c.n_manifolds;
             w->hint.n_colors = c.n_colors;
-            w->hint.n_active = c.n_active;
+            if (c.n_active) w->hint.n_active = c.n_active;
             if (full) w->hint.full_rounds = c.color_rounds; else w->hint.color_rounds = c.color_rounds;
             for (int q = 0; q < kMaxColors; ++q) w->hint.color_count[q] = c.color_count[q];
         }

@@ -17,6 +17,8 @@ namespace phys {
 
 constexpr int kMaxColors = 64;  // == PHYS_MAX_COLORS of include/spec/contact_solve.h
 constexpr uint64_t kClusterMinBodies = 32768;  // below: the dataflow kernels win anyway (few launches' worth of rows)
+constexpr uint32_t kClusterDynamicPeriod = 8;  // cluster steps between two deals of the dynamic homes (a body that became active
+                                               // since has none and is served as another cluster's body: slower, never wrong)
 constexpr uint64_t kClusterMinManifolds = 200000;  // measured: C3 (230k manifolds, 15 colours) 0.61 ms against 0.66 with k_solve_flow
 constexpr uint32_t kClusterMaxSlots = 2496;    // bodies per cluster whose {v, w, x, I^-1} fit one CU's LDS (64 B each: 156 KiB; 13-bit slot field)
 
@@ -245,6 +247,8 @@ struct phys_world {
     uint32_t cluster_count = 0, cluster_slots = 0;  // 0 clusters: not available for this scene (dynamic: set per update)
     bool cluster_dynamic = false;           // clusters are remade every update from the bodies that have manifolds (cluster.hip)
     int cluster_cus = 0;                    // CUs of the device (dynamic planning)
+    uint32_t cluster_age = 0;               // cluster steps since the homes were dealt out (dynamic: remade every kClusterDynamicPeriod)
+    bool cluster_homes_valid = false;
     uint64_t cluster_cap_limit = 0;         // PHYS_DEBUG_CLUSTER_CAP: fewer homes than the LDS would hold (tests)
     phys::DevBuf<uint32_t> active_flag, active_rank;  // n + 4 each: flag / exclusive rank in the broad phase's bucket order
     bool cluster_step = false;                      // this update's rows are in (cluster, colour) order
