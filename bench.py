@@ -451,6 +451,10 @@ def main():
     rehearsal = os.environ.get("PHYS_BENCH_REHEARSAL") == "1"
     if rehearsal:
         local_rank = 0
+        # several PROCESSES on one GPU: the cluster solver needs all its workgroups resident at once and cannot know of
+        # another process's launch (inside one process its launches are chained); the rehearsal is about the exchange
+        if world_size > 1:
+            os.environ.setdefault("PHYS_DEBUG_NO_CLUSTER", "1")
     # PHYS_BENCH_FORCE_DIST=1: take the sharded path (RCCL collective included) even with one rank, so the
     # N > 1 code is exercised end to end on a one-GPU box
     sharded = world_size > 1 or os.environ.get("PHYS_BENCH_FORCE_DIST") == "1"

@@ -4,7 +4,7 @@
 set -e
 timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
 timeout -k 10 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
-./tools/profile_all.sh
+./tools/profile_all.sh c5 t1m c3 c2
 timeout -k 10 900 python bench.py > gpurun_out/bench_final.log 2>&1
 echo "bench done"
 # N = 2 rehearsal of the sharded flow on this one GPU (gloo over pinned host buffers), and the one-rank RCCL path
