@@ -16,6 +16,8 @@
 #include <algorithm>
 #include <vector>
 
+#include <cstdlib>
+
 #include "kernels.hpp"
 
 namespace phys {
@@ -663,7 +665,9 @@ void launch_broadphase(phys_world* w) {
     build_sorted_grid(w);
     // small scenes are latency-bound: 4 lanes per body shorten the dependent chain; large scenes are
     // throughput-bound: one lane per body does the least total work
-    if (n <= 200000u) {
+    static const int pair_lanes_env = getenv("PHYS_DEBUG_PAIR_LANES") ? atoi(getenv("PHYS_DEBUG_PAIR_LANES")) : 0;  // measurements
+    // (measured: one lane per body is the faster one already at 100k bodies - C3: 0.051 against 0.089 ms)
+    if (pair_lanes_env ? pair_lanes_env == 4 : n <= 65536u) {
         PHYS_PROF(w, PHYS_STAGE_PAIRS);
         hipLaunchKernelGGL((k_find_pairs<4>), dim3((unsigned)(((uint64_t)n * 4 + kPairThreads - 1) / kPairThreads)), dim3(kPairThreads), 0, s,
                            w->bucket_start.p, T, axis_mask, w->sorted_ids.p, w->sorted_box.p, w->pairs.p, w->max_pairs, w->counters.p);

@@ -36,6 +36,8 @@ VARIANTS = {
     "dyn_cap": {"PHYS_DEBUG_CLUSTER_DYNAMIC": "1", "PHYS_DEBUG_CLUSTER_CAP": "60000"},  # ... with homes for 60k bodies only
     "flow_pipe": {"PHYS_DEBUG_FLOW_MAX": "100000000", "PHYS_DEBUG_NO_CLUSTER": "1", "PHYS_DEBUG_FLOW_PIPELINE": "1"},
     "flow_nopipe": {"PHYS_DEBUG_FLOW_MAX": "100000000", "PHYS_DEBUG_NO_CLUSTER": "1", "PHYS_DEBUG_FLOW_PIPELINE": "0"},
+    "pairs4": {"PHYS_DEBUG_PAIR_LANES": "4"},
+    "pairs1": {"PHYS_DEBUG_PAIR_LANES": "1"},
     "np128": {"PHYS_DEBUG_NP_THREADS": "128"},
     "np256": {"PHYS_DEBUG_NP_THREADS": "256"},
     "no_ctab": {"PHYS_DEBUG_NO_CTAB": "1"},   # timing of the rows stage without the colour-table build (colours differ)
