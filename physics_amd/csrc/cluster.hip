@@ -362,7 +362,11 @@ __global__ __launch_bounds__(kClusterThreads, DIAG ? kClusterPerCuDiag : kCluste
     bool dead = false;
     // (Measured and dropped, all bit-identical: touching the next rows into the L2, 3.18 vs 2.52 ms on C5; two lanes per
     // row, the halves of the relative velocity exchanged by DPP, four workgroups per CU: 2.99 vs 2.20 - 1.5x the load
-    // instructions and the scalar part of every row done twice; rotating the wave a colour segment starts on: no change.)
+    // instructions and the scalar part of every row done twice; rotating the wave a colour segment starts on: no change;
+    // FOUR lanes per row (lane q owns one of vA, wA, vB, wB as in k_solve_flow_quad) for scenes with 25-60 rows per cluster
+    // and colour step: 0.74 vs 0.60 ms on C3, 1.15 vs 0.62 on the 1M cubes - a quad's second row in one step is not fetched
+    // ahead, and four times the lanes issue four times the loads, polls and LDS traffic for a chain that the hand-off, not
+    // the arithmetic, dominates.)
     //
     // ROWS ARE FETCHED ONE OR TWO COLOUR STEPS AHEAD. A colour step of a cluster has fewer rows than the workgroup has
     // lanes (C5: ~130 of 256), and what a step costs is a chain - row fetch (2-3 us from HBM), LDS, ~1500 dependent
