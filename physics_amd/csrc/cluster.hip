@@ -148,6 +148,7 @@ int32_t cluster_assign(phys_world* w, const float* pos /* host, 3 * n_owned */) 
 // ---- dynamic clusters: plan (host, from the lagged count of active bodies) and assignment (device, this update) ----
 bool cluster_plan_dynamic(phys_world* w) {
     if (!w->cluster_dynamic) return false;
+    if (!w->sorted_grid_valid) return false;  // the deal reads the bucket order of this update's broad phase (sorted grid only)
     // the homes stay for kClusterDynamicPeriod cluster steps (a pile changes slowly; the deal is three passes over all
     // bodies); the plan is only made when they are dealt out again
     if (w->cluster_homes_valid && w->cluster_age < kClusterDynamicPeriod) return true;
