@@ -43,7 +43,9 @@ __global__ __launch_bounds__(kNpThreads) void k_narrowphase(
     uint32_t cache_mask /* 0 = keep nothing this update */, uint32_t stamp /* of this update */,
     uint32_t* __restrict__ unc_list /* ids of the manifolds that did not keep a colour: round 0 of the colouring */,
     StepCounters* __restrict__ ctr) {
-    __shared__ uint32_t wcount[kNpThreads / 64], wpts[kNpThreads / 64], wground[kNpThreads / 64], wunc[kNpThreads / 64];
+    // per-wave totals of a trip, in two sets used alternately: a wave may start the next trip (and post its totals) while
+    // another still reads this trip's to place its manifolds - there is no barrier at the end of a trip any more
+    __shared__ uint32_t wtot[2][4][kNpThreads / 64];
     __shared__ uint32_t block_base, unc_base;
     // polygon-clipper scratch in LDS: one 56-dword slice per lane at an odd (57) dword stride, so the lanes of
     // a wave hit distinct banks; private scratch memory would go through L1/L2 instead
@@ -56,8 +58,13 @@ __global__ __launch_bounds__(kNpThreads) void k_narrowphase(
     const uint32_t n_pairs = (uint64_t)np_raw < max_pairs ? np_raw : (uint32_t)max_pairs;
     const uint32_t total = n_ground + n_pairs;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (uint32_t base = blockIdx.x * kNpThreads; base < total; base += gridDim.x * kNpThreads) {
+    uint32_t trip = 0;
+    for (uint32_t base = blockIdx.x * kNpThreads; base < total; base += gridDim.x * kNpThreads, ++trip) {
         const uint32_t idx = base + threadIdx.x;
+        uint32_t* wcount = wtot[trip & 1u][0];
+        uint32_t* wpts = wtot[trip & 1u][1];
+        uint32_t* wground = wtot[trip & 1u][2];
+        uint32_t* wunc = wtot[trip & 1u][3];
         manifold_t m;
         m.count = 0;
         uint32_t a = 0, b = PHYS_GROUND_ID;
@@ -92,8 +99,50 @@ __global__ __launch_bounds__(kNpThreads) void k_narrowphase(
             }
         }
         const bool has = m.count > 0;
+        // ---- everything of a manifold that does not need its slot, BEFORE the workgroup's slot reservation: the kept
+        // colour (table entry asked for above; re-stamped here), the colour's mark at the two bodies, or round 0 of the
+        // colouring. Their round trips then overlap the reservation's instead of following it (the stage is a chain of
+        // dependent round trips at 12 waves per CU: one reservation with one barrier per trip instead of two with four).
+        // A manifold that turns out to be beyond the capacity has then left its marks too: that update is flagged, its
+        // solve skipped and its new manifolds never reach the table, so nothing of it survives.
+        unsigned long long prio = 0ull, seen_a = 0ull, seen_b = 0ull, bit = 0ull;
+        uint32_t col = kUncolored;
+        bool uncolored = false;
+        if (has) {
+            prio = color_priority(a, b);
+            // persistent colouring (contact_solve.h): a manifold that existed in the previous update keeps its
+            // colour - exact 64-bit key match in the table, stamped by the previous update; re-stamped here
+            if (cache_mask) {
+                const unsigned long long key = ((unsigned long long)a << 32) | b;
+                uint32_t h = (uint32_t)(prio >> 20) & cache_mask;
+                for (;;) {
+                    const ulonglong2 e = (have_early && h == early_h) ? early : cache[h];
+                    have_early = false;
+                    if (e.x == key) {
+                        if ((uint32_t)(e.y >> 32) + 1u == stamp) {
+                            col = (uint32_t)e.y;
+                            cache[h].y = ((unsigned long long)stamp << 32) | col;
+                        }
+                        break;  // a dead entry of this key: no live one follows
+                    }
+                    if (e.x == ~0ull) break;  // empty slot: never seen
+                    h = (h + 1) & cache_mask;
+                }
+            }
+            if (col != kUncolored) {
+                bit = 1ull << col;
+                seen_a = atomicOr(&used[a], bit);  // looked at after the barrier below
+                if (b != PHYS_GROUND_ID) seen_b = atomicOr(&used[b], bit);
+            } else {
+                uncolored = true;
+                // round 0 of the colouring: per-body maximum priority (order-independent u64 max)
+                atomicMax(&top0[a], prio);
+                if (b != PHYS_GROUND_ID) atomicMax(&top0[b], prio);
+            }
+        }
         const unsigned long long mask = __ballot(has);
         const unsigned long long gmask = __ballot(has && b == PHYS_GROUND_ID);
+        const unsigned long long umask = __ballot(uncolored);
         // contact points of this wave (for the stats counter)
         uint32_t pts = has ? (uint32_t)m.count : 0u;
 #pragma unroll
@@ -102,74 +151,40 @@ __global__ __launch_bounds__(kNpThreads) void k_narrowphase(
             wcount[wave] = (uint32_t)__popcll(mask);
             wpts[wave] = pts;
             wground[wave] = (uint32_t)__popcll(gmask);
+            wunc[wave] = (uint32_t)__popcll(umask);
         }
         __syncthreads();
         if (threadIdx.x == 0) {
             // one set of global atomics per workgroup: same-address atomics serialise chip-wide
-            uint32_t t = 0, tp = 0, tg = 0;
-            for (int k = 0; k < kNpThreads / 64; ++k) { t += wcount[k]; tp += wpts[k]; tg += wground[k]; }
-            uint32_t bb = 0;
+            uint32_t t = 0, tp = 0, tg = 0, tu = 0;
+            for (int k = 0; k < kNpThreads / 64; ++k) { t += wcount[k]; tp += wpts[k]; tg += wground[k]; tu += wunc[k]; }
+            uint32_t bb = 0, ub = 0;
+            if (t) bb = atomicAdd(&ctr->n_manifolds, t);
+            if (tu) ub = atomicAdd(&ctr->unc_count[0], tu);  // this workgroup's stretch of the round-0 list
             if (t) {
-                bb = atomicAdd(&ctr->n_manifolds, t);
                 const uint64_t room = (uint64_t)bb < max_manifolds ? max_manifolds - bb : 0;
                 const uint32_t stored = (uint64_t)t <= room ? t : (uint32_t)room;
                 if (stored != t) flag_overflow(ctr, 2u);
                 atomicAdd(&ctr->n_contacts, tp);
                 if (tg) atomicAdd(&ctr->n_ground_manifolds, tg);
+                if (tu) atomicAdd(&ctr->n_uncolored, tu);
             }
             block_base = bb;
+            unc_base = ub;
         }
         __syncthreads();
-        bool uncolored = false;
-        uint32_t my_slot = 0;
         if (has) {
-            uint32_t woff = 0;
-            for (int k = 0; k < wave; ++k) woff += wcount[k];
+            uint32_t woff = 0, uoff = 0;
+            for (int k = 0; k < wave; ++k) { woff += wcount[k]; uoff += wunc[k]; }
             const uint64_t slot = (uint64_t)block_base + woff + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
             if (slot < max_manifolds) {
-                my_slot = (uint32_t)slot;
                 man_a[slot] = a;
                 man_b[slot] = b;
-                const unsigned long long prio = color_priority(a, b);
                 man_prio[slot] = prio;
-                // persistent colouring (contact_solve.h): a manifold that existed in the previous update keeps its
-                // colour - exact 64-bit key match in the table, stamped by the previous update; re-stamped here
-                uint32_t col = kUncolored;
-                if (cache_mask) {
-                    const unsigned long long key = ((unsigned long long)a << 32) | b;
-                    uint32_t h = (uint32_t)(prio >> 20) & cache_mask;
-                    for (;;) {
-                        const ulonglong2 e = (have_early && h == early_h) ? early : cache[h];
-                        have_early = false;
-                        if (e.x == key) {
-                            if ((uint32_t)(e.y >> 32) + 1u == stamp) {
-                                col = (uint32_t)e.y;
-                                cache[h].y = ((unsigned long long)stamp << 32) | col;
-                            }
-                            break;  // a dead entry of this key: no live one follows
-                        }
-                        if (e.x == ~0ull) break;  // empty slot: never seen
-                        h = (h + 1) & cache_mask;
-                    }
-                }
                 man_color[slot] = col;
-                if (col != kUncolored) {
-                    // order-independent. A kept colour that is ALREADY in use at one of the bodies means the previous
-                    // colouring was not proper (it saturated at PHYS_MAX_COLORS): two rows of one colour on one body
-                    // would race in the solver, so the step is flagged like any other colour overflow (no solve)
-                    const unsigned long long bit = 1ull << col;
-                    bool clash = (atomicOr(&used[a], bit) & bit) != 0ull;
-                    if (b != PHYS_GROUND_ID) clash = ((atomicOr(&used[b], bit) & bit) != 0ull) || clash;
-                    if (clash) flag_overflow(ctr, 4u);
-                } else {
-                    uncolored = true;
-                    // round 0 of the colouring: per-body maximum priority (order-independent u64 max)
-                    atomicMax(&top0[a], prio);
-                    if (b != PHYS_GROUND_ID) atomicMax(&top0[b], prio);
-                }
                 // (Measured and dropped: staging the records of a wave in LDS and copying them out as whole 128-byte lines -
                 // 4.5 write requests per manifold become 2 - left the kernel at 0.52 ms on C5: it waits on its chain of
-                // dependent round trips - pair, shapes, slot atomic, table entry, used masks - not on the write path.)
+                // dependent round trips, not on the write path.)
                 float4* o = reinterpret_cast<float4*>(man_geo) + 8 * slot;  // one 128-byte line per manifold, 96 bytes used
                 o[0] = make_float4(__uint_as_float(a), __uint_as_float(b), __uint_as_float((uint32_t)m.count),
                                    __uint_as_float(col != kUncolored ? 1u : 0u) /* colour kept: already in the table */);
@@ -177,24 +192,21 @@ __global__ __launch_bounds__(kNpThreads) void k_narrowphase(
 #pragma unroll
                 for (int k = 0; k < 4; ++k) o[2 + k] = make_float4(m.pt[k].x, m.pt[k].y, m.pt[k].z, m.depth[k]);
             }
-        }
-        const unsigned long long umask = __ballot(uncolored);
-        if (lane == 0) wunc[wave] = (uint32_t)__popcll(umask);
-        __syncthreads();  // wcount / block_base are reused by the next trip
-        if (threadIdx.x == 0) {
-            uint32_t t = 0;
-            for (int k = 0; k < kNpThreads / 64; ++k) t += wunc[k];
-            if (t) {
-                atomicAdd(&ctr->n_uncolored, t);
-                unc_base = atomicAdd(&ctr->unc_count[0], t);  // this workgroup's stretch of the round-0 list
+            if (uncolored) {
+                // (a manifold beyond the capacity - update flagged, never solved - names the last slot: the list must hold
+                // ids of stored manifolds only, whatever else happens to that update)
+                const uint32_t at = unc_base + uoff + (uint32_t)__popcll(umask & ((1ull << lane) - 1ull));
+                unc_list[at < max_manifolds ? at : (uint32_t)max_manifolds - 1u] =
+                    slot < max_manifolds ? (uint32_t)slot : (uint32_t)max_manifolds - 1u;
+            } else if (((seen_a | seen_b) & bit) != 0ull) {
+                // order-independent. A kept colour that was ALREADY in use at one of the bodies means the previous
+                // colouring was not proper (it saturated at PHYS_MAX_COLORS): two rows of one colour on one body
+                // would race in the solver, so the step is flagged like any other colour overflow (no solve)
+                flag_overflow(ctr, 4u);
             }
         }
-        __syncthreads();  // (wunc is rewritten only after the next trip's first barrier)
-        if (uncolored) {
-            uint32_t at = unc_base + (uint32_t)__popcll(umask & ((1ull << lane) - 1ull));
-            for (int k = 0; k < wave; ++k) at += wunc[k];
-            unc_list[at] = my_slot;  // at < stored manifolds <= max_manifolds
-        }
+        // (block_base / unc_base are rewritten behind the next trip's first barrier, which every wave reaches only after it
+        // has placed this trip's manifolds; the per-wave totals alternate between two sets)
     }
 }
 
