@@ -173,6 +173,11 @@ bool cluster_plan_dynamic(phys_world* w) {
         const size_t per_wg = (cluster_lds_bytes(slots) + 1023) / 1024 * 1024;
         const bool ok = per_wg * (size_t)per_cu <= kClusterLdsPerCu && slots <= kClusterMaxSlots;
         if (ok || per_cu == 1) {
+            // Only while the homes fit with the FULL number of workgroups per CU. Measured on the growing 1M-cube pile: the
+            // moment the plan has to go to two or one larger workgroups per CU the per-colour launches are faster (2.10
+            // against 2.33 ms at 430k active bodies, 2.66 against 3.30 at 500k; with half the bodies homeless 3.61 against
+            // 4.08) - fewer workgroups hide less of each other's colour steps. (A capacity set for tests is obeyed.)
+            if ((!ok || per_cu < per_cu_max) && !w->cluster_cap_limit && !per_cu_env) return false;
             if (!ok) slots = kClusterMaxSlots / 64u * 64u;  // one workgroup per CU, as many homes as its LDS holds
             w->cluster_count = clusters;
             w->cluster_slots = slots;
