@@ -10,6 +10,13 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # A fresh checkout has no built library (the .so files are git-ignored): build once, here, where hipcc cross-compiles
+    # gfx950 without a GPU. The product itself never builds or falls back on its own (physics_amd._abi raises); this is
+    # the test session doing what `__graft_entry__.build()` does. The GPU box runs with the prebuilt files of the snapshot.
+    from physics_amd import _abi
+    if not os.path.exists(_abi.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
 
 
 @pytest.fixture(scope="session")
