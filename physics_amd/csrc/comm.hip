@@ -260,7 +260,10 @@ int32_t phys_comm_set_neighbours(phys_comm* c, int32_t enable) {
     PHYS_HIP_TRY(hipSetDevice(c->device));
     c->neighbours = enable != 0;
     // a block nobody sends into (first / last rank, or one rank alone) reads as "no records" for ever
-    if (c->neighbours) PHYS_HIP_TRY(hipMemset(c->recv, 0xFF, (size_t)2 * c->cap * PHYS_HALO_BODY_RECORD_BYTES));
+    if (c->neighbours) {
+        PHYS_HIP_TRY(hipMemset(c->recv, 0xFF, (size_t)2 * c->cap * PHYS_HALO_BODY_RECORD_BYTES));
+        PHYS_HIP_TRY(hipDeviceSynchronize());  // set-up call: the fill is in place before any world's stream reads the blocks
+    }
     return PHYS_OK;
 }
 
