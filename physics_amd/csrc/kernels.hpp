@@ -82,6 +82,7 @@ __device__ __forceinline__ m33 ld_inertia_c(const float* __restrict__ p, uint32_
 // Round 1-2a rebuilt a table per update inside k_rows_build (an atomic and two scattered stores per manifold, plus the
 // sparse clear of the other table): 0.26 of k_rows_build's 0.50 ms on C5. The layout depends on arrival order, the
 // answers (exact key + stamp matches) do not.
+constexpr uint32_t kColorTableMaxWalk = 4096;  // slots a look-up may walk before it gives up (a full table must not hang a wave)
 struct ColorTableJob {
     ulonglong2* tab;  // null: nothing to do
     uint32_t mask;
@@ -93,7 +94,8 @@ __device__ __forceinline__ void color_table_insert(const ColorTableJob& job, uin
     const unsigned long long key = ((unsigned long long)a << 32) | b;
     const unsigned long long val = ((unsigned long long)job.stamp << 32) | job.man_color[m];
     uint32_t h = (uint32_t)(job.man_prio[m] >> 20) & job.mask;
-    for (;;) {
+    // bounded (see the walk in k_narrowphase): a manifold that finds no slot is simply coloured afresh next time
+    for (uint32_t walked = 0; walked < 4u * kColorTableMaxWalk; ++walked) {
         unsigned long long* vp = &job.tab[h].y;
         const unsigned long long seen = __hip_atomic_load(vp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if ((uint32_t)(seen >> 32) != job.stamp && atomicCAS(vp, seen, val) == seen) {

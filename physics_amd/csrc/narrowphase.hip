@@ -115,7 +115,10 @@ __global__ __launch_bounds__(kNpThreads) void k_narrowphase(
             if (cache_mask) {
                 const unsigned long long key = ((unsigned long long)a << 32) | b;
                 uint32_t h = (uint32_t)(prio >> 20) & cache_mask;
-                for (;;) {
+                // bounded walk: the table is reset every PHYS_COLOR_CACHE_PERIOD updates and holds 1.5 slots per manifold
+                // slot, but a chain of live and dead entries without an empty slot must end the walk, not hang the GPU
+                // (a pair given up on is coloured afresh: still a proper colouring)
+                for (uint32_t walked = 0; walked < kColorTableMaxWalk; ++walked) {
                     const ulonglong2 e = (have_early && h == early_h) ? early : cache[h];
                     have_early = false;
                     if (e.x == key) {
