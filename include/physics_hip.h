@@ -52,6 +52,12 @@ extern "C" {
 #define PHYS_FLAG_BROADPHASE_ONLY 0x8u /* with COLLISIONS: stop after the candidate-pair list */
 #define PHYS_FLAG_SOLVER_PER_COLOR 0x10u /* contact solver as one launch per colour class instead of the single-launch
                                             dataflow kernel; same order of updates per body, bit-identical results */
+#define PHYS_FLAG_SHARED_GPU 0x20u       /* other work (another stream of the application, another process) may run on
+                                            this GPU beside phys_update. The cluster solver - one launch whose workgroups
+                                            must all be resident - then starts all-or-nothing (every workgroup is counted
+                                            in before anything is written; a launch that does not fit is called off and
+                                            tried again): ~0.06 ms per update. Implied when the process holds several
+                                            worlds on one device. Same results either way. */
 
 typedef struct phys_config {
     uint32_t abi_version;       /* PHYS_ABI_VERSION */

@@ -2,6 +2,7 @@
 // argument checking, uploads, and the per-frame launch sequence. All compute is in HIP kernels; there
 // is no CPU fallback anywhere in this library.
 #include <algorithm>
+#include <atomic>
 #include <cstring>
 #include <limits>
 #include <string>
@@ -82,6 +83,11 @@ void poll_snapshots(phys_world* w) {
 }
 }  // namespace phys
 
+namespace phys {
+static std::atomic<int> g_worlds[64];
+int worlds_on_device(int device) { return g_worlds[device & 63].load(std::memory_order_relaxed); }
+}  // namespace phys
+
 static int32_t fail(int32_t code, const char* msg) {
     set_error(msg);
     return code;
@@ -150,12 +156,14 @@ int32_t phys_create(const phys_config* cfg, phys_world** out) {
     if (e == hipSuccess) e = hipMemsetAsync(w->counters.p, 0, sizeof(StepCounters), w->stream);
     if (e != hipSuccess) { delete w; return fail(PHYS_ERR_HIP, "counter allocation failed"); }
     std::memset(w->h_counters, 0, sizeof(StepCounters));
+    phys::g_worlds[w->device & 63].fetch_add(1);
     *out = w;
     return PHYS_OK;
 }
 
 int32_t phys_destroy(phys_world* w) {
     if (!w) return PHYS_OK;
+    phys::g_worlds[w->device & 63].fetch_sub(1);
     (void)hipSetDevice(w->device);
     if (w->stream) (void)hipStreamSynchronize(w->stream);
     DevBuf<float>* fb[] = {&w->pos, &w->rot, &w->vel, &w->force, &w->torque, &w->inv_inertia_diag,
@@ -417,6 +425,22 @@ int32_t phys_sync(phys_world* w) {
                                    std::to_string(g[0]) + ": a " + std::to_string(g[1]) + ", b " + std::to_string(g[2]) + ", points " +
                                    std::to_string(g[3]) + "; colour " + std::to_string(g[6]) + " rows [" + std::to_string(g[4]) + ", " +
                                    std::to_string(g[5]) + "), tile base " + std::to_string(g[7]) + ")").c_str());
+    }
+    if (w->h_counters->debug[0] != 0u) {  // reported below: the next event may leave its own note
+        PHYS_HIP_TRY(hipMemsetAsync(w->counters.p->debug, 0, sizeof(w->counters.p->debug), w->stream));
+        PHYS_HIP_TRY(hipStreamSynchronize(w->stream));
+    }
+    if ((bits & 16u) && w->h_counters->debug[0] == 0xC1u) {
+        const uint32_t* g = w->h_counters->debug;  // what the first lane of k_solve_cluster to give up was waiting for
+        return fail(PHYS_ERR_HIP, ("contact solver hand-off timed out (k_solve_cluster) in a step since the last phys_sync; velocities "
+                                   "are invalid from that step on. First lane to give up: cluster " + std::to_string(g[1] & 0xFFFFu) + " of " + std::to_string(g[1] >> 16) + ", row " +
+                                   std::to_string(g[2]) + ", bodies " + std::to_string(g[3]) + " / " + std::to_string(g[4]) +
+                                   ", tickets " + std::to_string(g[5] & 0xFFFFu) + " / " + std::to_string(g[5] >> 16) + ", waiting A/B " +
+                                   std::to_string(g[6] & 1u) + "/" + std::to_string((g[6] >> 1) & 1u) + ", modes " +
+                                   std::to_string((g[6] >> 4) & 3u) + "/" + std::to_string((g[6] >> 8) & 3u) + ", tags seen " +
+                                   std::to_string(g[6] >> 16) + " / " + std::to_string(g[7] >> 16) + ", iteration " +
+                                   std::to_string((g[7] >> 8) & 0xFFu) + ", colour " + std::to_string(g[7] & 0xFFu) +
+                                   ". If other work shares this GPU with phys_update, create the world with PHYS_FLAG_SHARED_GPU").c_str());
     }
     if (bits & 16u)
         return fail(PHYS_ERR_HIP, "contact solver hand-off timed out (k_solve_flow) in a step since the last phys_sync; "

@@ -22,6 +22,7 @@
 // bounded (timeout -> overflow bit 4 -> PHYS_ERR_HIP). Same arithmetic (solve_manifold_lazy), same order per body:
 // bit-identical to the other solver paths.
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <mutex>
 #include <vector>
@@ -224,12 +225,18 @@ __global__ __launch_bounds__(256) void k_cluster_keys(uint64_t max_manifolds, co
                                                       const uint32_t* __restrict__ man_b, const uint32_t* __restrict__ man_color,
                                                       const uint32_t* __restrict__ cluster_slot, uint32_t slots, uint32_t clusters,
                                                       uint32_t* __restrict__ seg_count, uint32_t* __restrict__ man_rank,
-                                                      uint32_t* __restrict__ body_shared, const StepCounters* __restrict__ ctr) {
+                                                      uint32_t* __restrict__ body_shared, StepCounters* __restrict__ ctr) {
+    // manifolds per colour and the number of colours ride along (a cluster step has no use for the colour-major sort
+    // that k_color_hist / k_color_offsets serve, only for these counters): one LDS histogram per workgroup
+    __shared__ uint32_t s_hist[PHYS_MAX_COLORS];
+    if (threadIdx.x < PHYS_MAX_COLORS) s_hist[threadIdx.x] = 0u;
+    __syncthreads();
     const uint32_t raw = ctr->n_manifolds;
     const uint32_t M = (uint64_t)raw < max_manifolds ? raw : (uint32_t)max_manifolds;
     for (uint32_t m = blockIdx.x * blockDim.x + threadIdx.x; m < M; m += gridDim.x * blockDim.x) {
         const uint32_t a = man_a[m], b = man_b[m], c = man_color[m];
         if (c >= (uint32_t)PHYS_MAX_COLORS) { man_rank[m] = 0xFFFFFFFFu; continue; }
+        atomicAdd(&s_hist[c], 1u);
         const uint32_t ha = cluster_home(cluster_slot, a, slots);
         const uint32_t hb = b == PHYS_GROUND_ID ? kNoHome : cluster_home(cluster_slot, b, slots);
         const uint32_t owner = cluster_row_owner(a, ha, hb, clusters);
@@ -239,6 +246,11 @@ __global__ __launch_bounds__(256) void k_cluster_keys(uint64_t max_manifolds, co
         // that body is `shared`, and the colours of those rows are its remote colours (two halves of a 64-bit mask).
         // (A's home owns the row whenever A has one.)
         if (hb != kNoHome && hb != owner) atomicOr(&body_shared[2 * (size_t)b + (c >> 5)], 1u << (c & 31u));
+    }
+    __syncthreads();
+    if (threadIdx.x < PHYS_MAX_COLORS && s_hist[threadIdx.x]) {
+        atomicAdd(&ctr->color_count[threadIdx.x], s_hist[threadIdx.x]);
+        atomicMax(&ctr->n_colors, threadIdx.x + 1u);
     }
 }
 
@@ -295,10 +307,11 @@ void launch_cluster_sort(phys_world* w, unsigned blocks) {
 // ---- the solver ----------------------------------------------------------------------------------------------
 typedef uint32_t u32x4c __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ u32x4c ld_gran(__amdgpu_buffer_rsrc_t r, uint32_t byte_off) {
-    // agent scope (sc1): the other XCDs' write-through stores are seen, this XCD's L2 is not trusted. (The volatile
-    // form adds sc0 = system scope.) The compiler barrier makes every poll a new load.
-    asm volatile("" ::: "memory");
-    return __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, (int)0x10);
+    // sc0 | sc1 (what the volatile form emits): read past this XCD's L2. With sc1 alone ("agent scope") a poll could keep
+    // hitting a line its own XCD had cached before the other XCD's write-through store landed: one run in two of two
+    // worlds stepping side by side ended in the hand-off time-out (tools/ghost_cluster_stress.py), none with this form -
+    // and the scope made no difference in time.
+    return __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, (int)0x80000010);
 }
 __device__ __forceinline__ void st_gran(__amdgpu_buffer_rsrc_t r, uint32_t byte_off, v3 v, uint32_t tag) {
     u32x4c g;
@@ -334,11 +347,13 @@ __global__ __launch_bounds__(kClusterThreads, DIAG ? kClusterPerCuDiag : kCluste
                                                                   const uint32_t* __restrict__ cluster_body,
                                                                   const uint32_t* __restrict__ body_shared,
                                                                   const uint32_t* __restrict__ seg_start, uint32_t slots,
-                                                                  long long timeout_ticks, uint32_t ablate) {
+                                                                  long long timeout_ticks, uint32_t ablate, uint32_t attempt,
+                                                                  uint32_t last_attempt, long long arrive_ticks) {
     extern __shared__ __attribute__((aligned(16))) float4 s_lds[];  // [4 * slots]: {v, tag} {w, 1/m} {x} {I^-1 diag};  then the segment table
     float4* s_body = s_lds;
     uint32_t* s_seg = reinterpret_cast<uint32_t*>(s_lds + 4 * (size_t)slots);  // PHYS_MAX_COLORS + 1 row offsets
     if (ctr->overflow) return;
+    if (attempt != 0u && ctr->cluster_state[attempt - 1u] == 1u) return;  // an earlier attempt went through (see below)
     const uint32_t cluster = blockIdx.x;
     const uint32_t n_colors = ctr->n_colors;
     const uint32_t etag = epoch << 16;
@@ -363,7 +378,47 @@ __global__ __launch_bounds__(kClusterThreads, DIAG ? kClusterPerCuDiag : kCluste
         s_body[4 * sl + 3] = e;
     }
     if (threadIdx.x <= (uint32_t)PHYS_MAX_COLORS) s_seg[threadIdx.x] = seg_start[(size_t)cluster * PHYS_MAX_COLORS + threadIdx.x];
-    __syncthreads();
+    // ---- ALL OR NOTHING. Every workgroup of this launch must be resident at once (they wait for each other's updates), and
+    // whether they are is not a matter of counts alone: registers are handed out in contiguous ranges, so workgroups of
+    // ANOTHER stream's kernels that run beside the start of this launch leave holes between this kernel's waves that never
+    // close (its waves stay until the end), and a CU then takes two of its workgroups instead of three - measured: in
+    // half of the runs of two worlds stepping side by side 1-2 of 520 workgroups never started, and the rest spun until the
+    // time-out (tools/ghost_cluster_stress.py; never when the launch began on an idle device; a cooperative launch does not
+    // help). So a launch first counts its workgroups in; nothing is written before ONE decision is made for all: go, once
+    // all have begun, or - if they have not within `arrive_ticks` - called off: everybody leaves, the holes close, and the
+    // next attempt (the host enqueues a few; the ones after a `go` return at once) starts on cleaner ground. Only the last
+    // attempt's failure is an error (overflow bit 4).
+    // (Counted in after the bodies have been read into LDS - that writes nothing outside the workgroup and overlaps the
+    // arrival of the others.)
+    {
+        __shared__ uint32_t s_go;
+        if (threadIdx.x == 0) {
+            bool solved = false;
+            for (uint32_t a = 0; a < attempt; ++a) solved = solved || __hip_atomic_load(&ctr->cluster_state[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1u;
+            uint32_t st = solved ? 2u : (arrive_ticks < 0 ? 1u : 0u);
+            if (!solved && arrive_ticks >= 0) {
+                atomicAdd(&ctr->cluster_arrived[attempt][blockIdx.x & 7u], 1u);
+                const long long t0 = wall_clock64();
+                for (;;) {
+                    st = __hip_atomic_load(&ctr->cluster_state[attempt], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (st != 0u) break;
+                    uint32_t in = 0;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) in += __hip_atomic_load(&ctr->cluster_arrived[attempt][k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (in >= gridDim.x) {
+                        atomicCAS(&ctr->cluster_state[attempt], 0u, 1u);
+                    } else if (wall_clock64() - t0 > arrive_ticks) {
+                        if (atomicCAS(&ctr->cluster_state[attempt], 0u, 2u) == 0u && last_attempt) flag_overflow(ctr, 16u);
+                    } else {
+                        __builtin_amdgcn_s_sleep(16);
+                    }
+                }
+            }
+            s_go = st == 1u ? 1u : 0u;
+        }
+        __syncthreads();
+        if (!s_go) return;
+    }
     const long long t_start = wall_clock64();
     bool dead = false;
     // (Measured and dropped, all bit-identical: touching the next rows into the L2, 3.18 vs 2.52 ms on C5; two lanes per
@@ -523,7 +578,17 @@ __global__ __launch_bounds__(kClusterThreads, DIAG ? kClusterPerCuDiag : kCluste
                         if ((++sweeps & 63u) == 0u) {
                             const bool gone = (wall_clock64() - t_start > timeout_ticks) ||
                                               (__hip_atomic_load(&ctr->overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 16u);
-                            if (gone) { flag_overflow(ctr, 16u); dead = true; needA = false; needB = false; }
+                            if (gone) {
+                                if (atomicCAS(&ctr->debug[0], 0u, 0xC1u) == 0u) {  // the first lane to give up says what it waited for
+                                    const uint32_t ga = needA ? ld_gran(rv, h.x * 32u).w : 0u, gb = needB ? ld_gran(rv, h.y * 32u).w : 0u;
+                                    ctr->debug[1] = cluster | (gridDim.x << 16);
+                                    ctr->debug[2] = d_row; ctr->debug[3] = h.x; ctr->debug[4] = h.y;
+                                    ctr->debug[5] = (tA & 0xFFFFu) | (tB << 16);
+                                    ctr->debug[6] = (needA ? 1u : 0u) | (needB ? 2u : 0u) | (modeA << 4) | (modeB << 8) | ((ga & 0xFFFFu) << 16);
+                                    ctr->debug[7] = (col & 0xFFu) | ((it & 0xFFu) << 8) | ((gb & 0xFFFFu) << 16);
+                                }
+                                flag_overflow(ctr, 16u); dead = true; needA = false; needB = false;
+                            }
                         }
                     }
                 }
@@ -605,14 +670,25 @@ void launch_solve_cluster(phys_world* w, void* row_all, uint64_t cap, float fric
     if (ev) (void)hipStreamWaitEvent(w->stream, ev, 0);
     else (void)hipEventCreateWithFlags(&ev, hipEventDisableTiming);
     struct Record { hipEvent_t e; hipStream_t s; ~Record() { if (e) (void)hipEventRecord(e, s); } } record{ev, w->stream};
-    if (diag)
-        hipLaunchKernelGGL(k_solve_cluster<true>, g, b, lds, w->stream, w->counters.p, w->cfg.solver_iterations, w->flow_epoch, rows, friction,
-                           inertia, stride, w->vel.p, w->pos.p, w->flow_vel.p, (uint32_t)w->n, w->cluster_body.p, w->body_shared.p,
-                           w->seg_start.p, w->cluster_slots, timeout_ticks, ablate);
-    else
-        hipLaunchKernelGGL(k_solve_cluster<false>, g, b, lds, w->stream, w->counters.p, w->cfg.solver_iterations, w->flow_epoch, rows, friction,
-                           inertia, stride, w->vel.p, w->pos.p, w->flow_vel.p, (uint32_t)w->n, w->cluster_body.p, w->body_shared.p,
-                           w->seg_start.p, w->cluster_slots, timeout_ticks, ablate);
+    // ... and the all-or-nothing start inside the kernel covers what runs beside a launch from other streams - where that
+    // can happen: several worlds of this process on the device, or PHYS_FLAG_SHARED_GPU. A world alone on its GPU starts
+    // every launch on an idle device (its own kernels run one after the other) and skips the count (C5: 0.09 ms, 1M cubes:
+    // 0.06 ms per update).
+    const bool guarded = worlds_on_device(w->device) > 1 || (w->cfg.flags & PHYS_FLAG_SHARED_GPU) != 0u;
+    const uint32_t kAttempts = guarded ? 2u : 1u;
+    for (uint32_t attempt = 0; attempt < kAttempts; ++attempt) {
+        const uint32_t last = attempt + 1 == kAttempts ? 1u : 0u;
+        // 100 MHz ticks: 0.5 ms, then 20 ms for the workgroups to come in (alone on the device they need ~10 us); < 0: no count
+        const long long arrive_ticks = !guarded ? -1ll : (attempt == 0 ? 50000ll : 2000000ll);
+        if (diag)
+            hipLaunchKernelGGL(k_solve_cluster<true>, g, b, lds, w->stream, w->counters.p, w->cfg.solver_iterations, w->flow_epoch, rows,
+                               friction, inertia, stride, w->vel.p, w->pos.p, w->flow_vel.p, (uint32_t)w->n, w->cluster_body.p,
+                               w->body_shared.p, w->seg_start.p, w->cluster_slots, timeout_ticks, ablate, attempt, last, arrive_ticks);
+        else
+            hipLaunchKernelGGL(k_solve_cluster<false>, g, b, lds, w->stream, w->counters.p, w->cfg.solver_iterations, w->flow_epoch, rows,
+                               friction, inertia, stride, w->vel.p, w->pos.p, w->flow_vel.p, (uint32_t)w->n, w->cluster_body.p,
+                               w->body_shared.p, w->seg_start.p, w->cluster_slots, timeout_ticks, ablate, attempt, last, arrive_ticks);
+    }
 }
 
 }  // namespace phys

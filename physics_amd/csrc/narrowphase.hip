@@ -815,10 +815,13 @@ void launch_coloring(phys_world* w) {
         nb = 1;
         while (nb < want && nb < (uint32_t)kSortBlocksMax) nb <<= 1;
     }
+    if (w->cluster_step) {
+        launch_cluster_sort(w, blocks * (kColorThreads / 256));  // rows by (owner cluster, colour); counts the colours too
+    } else {
     { PHYS_PROF(w, PHYS_STAGE_ROWS); hipLaunchKernelGGL(k_color_hist, dim3(nb), dim3(1024), 0, s, w->max_manifolds, w->man_color.p, w->color_block_hist.p, nb, w->counters.p); }
     { PHYS_PROF(w, PHYS_STAGE_ROWS); hipLaunchKernelGGL(k_color_offsets, dim3(1), dim3(1024), 0, s, w->color_block_hist.p, nb, w->counters.p); }
-    if (w->cluster_step) launch_cluster_sort(w, blocks * (kColorThreads / 256));  // rows by (cluster of body A, colour)
-    else { PHYS_PROF(w, PHYS_STAGE_ROWS); hipLaunchKernelGGL(k_color_place, dim3(nb), dim3(1024), 0, s, w->max_manifolds, w->man_color.p, w->color_block_hist.p, nb, w->row_src.p, w->counters.p); }
+    { PHYS_PROF(w, PHYS_STAGE_ROWS); hipLaunchKernelGGL(k_color_place, dim3(nb), dim3(1024), 0, s, w->max_manifolds, w->man_color.p, w->color_block_hist.p, nb, w->row_src.p, w->counters.p); }
+    }
     }
     {
         // the new manifolds of this update go into the colour table in k_rows_build (launch_solver): one launch less

@@ -74,6 +74,9 @@ struct StepCounters {
     uint32_t flow_ticket;    // k_solve_flow: next (iteration, row chunk) item to hand to a workgroup
     uint32_t n_grid_ovf;     // slot grid: bodies that found their bucket's four slots taken
     uint32_t n_active;       // owned bodies with at least one manifold in this update (dynamic clusters, cluster.hip)
+    uint32_t cluster_arrived[2][8];  // k_solve_cluster, per attempt: workgroups that have begun (eight counters: same-address
+                                     // atomics serialise chip-wide) ...
+    uint32_t cluster_state[2];       // ... and the launch's one decision: 0 undecided, 1 go (all are resident), 2 called off
     uint32_t unc_count[3];   // colouring rounds: length of the list of uncoloured manifolds read / written / cleared (rotating)
     uint32_t color_count[kMaxColors];  // manifolds per colour
     uint32_t color_start[kMaxColors + 1];
@@ -149,6 +152,9 @@ struct StepHint {
     uint32_t recent_pos = 0;
     uint32_t color_count[kMaxColors] = {};
 };
+
+// worlds alive per device in this process (abi.hip): two of them step on two streams, i.e. beside each other
+int worlds_on_device(int device);
 
 struct Constraint {
     uint32_t kind;  // 0 fix point, 1 fix orientation

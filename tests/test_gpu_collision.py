@@ -438,6 +438,30 @@ def test_cluster_solver_bit_exact_against_the_oracle_on_a_33k_tower():
     assert sw.n_manifolds > 300_000
 
 
+def test_guarded_start_of_the_cluster_solver_changes_nothing():
+    """PHYS_FLAG_SHARED_GPU (implied by a second world on the device): every workgroup of the cluster solver's launch is
+    counted in before anything is written, and a launch that cannot be resident as a whole is called off and tried again
+    (other streams' kernels beside the start of a launch leave register holes that cost it workgroups: DESIGN.md). Same
+    bits with and without, and the cluster solver runs in both."""
+    import physics_amd
+    from physics_amd import scenes
+    sc = scenes.c5(16, 130, 16)
+    states = []
+    for extra in (0, physics_amd.FLAG_SHARED_GPU):
+        w = physics_amd.World(sc.config(flags=sc.flags | extra))
+        sc.populate(w)
+        w.update_n(DT, 8)
+        w.profile_enable(True)
+        w.update_n(DT, 6)
+        w.sync()
+        prof, _ = w.profile_get()
+        assert "solve_cluster" in prof
+        states.append(w.get_transforms() + w.get_velocities())
+        w.close()
+    for a, b in zip(states[0], states[1]):
+        assert np.array_equal(a, b)
+
+
 @pytest.mark.parametrize("cap", ["", "9000"])
 def test_dynamic_clusters_equal_the_per_colour_kernels(cap):
     """Scenes whose bodies outnumber the chip's LDS (the 1M-cube drop) get DYNAMIC clusters: homes are dealt out every
