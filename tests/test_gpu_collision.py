@@ -462,6 +462,40 @@ def test_guarded_start_of_the_cluster_solver_changes_nothing():
         assert np.array_equal(a, b)
 
 
+def test_cluster_solver_under_a_stream_of_foreign_kernels():
+    """The case PHYS_FLAG_SHARED_GPU is for: bf16 GEMMs and small element-wise kernels are launched on another stream
+    right before every update of a 33k tower on the cluster solver, so that some of them run beside the START of its
+    launch. No hand-off time-out, and the same bits as a world stepping on a quiet GPU."""
+    import torch
+    import physics_amd
+    from physics_amd import scenes
+    sc = scenes.c5(16, 130, 16)
+    busy = physics_amd.World(sc.config(flags=sc.flags | physics_amd.FLAG_SHARED_GPU))
+    sc.populate(busy)
+    side = torch.cuda.Stream()
+    m = torch.randn(1024, 1024, device="cuda", dtype=torch.bfloat16)
+    v = torch.zeros(1 << 20, device="cuda")
+    for step in range(40):
+        with torch.cuda.stream(side):
+            for _ in range(6):
+                m2 = m @ m
+                v.add_(1.0)
+        busy.update(DT)
+        if step % 8 == 7:
+            busy.sync()  # raises on a time-out
+    busy.sync()
+    torch.cuda.synchronize()
+    busy_state = busy.get_transforms() + busy.get_velocities()
+    busy.close()
+    quiet = physics_amd.World(sc.config())
+    sc.populate(quiet)
+    quiet.update_n(DT, 40)
+    quiet.sync()
+    for a, b in zip(busy_state, quiet.get_transforms() + quiet.get_velocities()):
+        assert np.array_equal(a, b)
+    quiet.close()
+
+
 @pytest.mark.parametrize("cap", ["", "9000"])
 def test_dynamic_clusters_equal_the_per_colour_kernels(cap):
     """Scenes whose bodies outnumber the chip's LDS (the 1M-cube drop) get DYNAMIC clusters: homes are dealt out every
