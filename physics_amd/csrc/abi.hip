@@ -437,8 +437,7 @@ int32_t phys_sync(phys_world* w) {
                                    std::to_string(g[2]) + ", bodies " + std::to_string(g[3]) + " / " + std::to_string(g[4]) +
                                    ", tickets " + std::to_string(g[5] & 0xFFFFu) + " / " + std::to_string(g[5] >> 16) + ", waiting A/B " +
                                    std::to_string(g[6] & 1u) + "/" + std::to_string((g[6] >> 1) & 1u) + ", modes " +
-                                   std::to_string((g[6] >> 4) & 3u) + "/" + std::to_string((g[6] >> 8) & 3u) + ", tags seen " +
-                                   std::to_string(g[6] >> 16) + " / " + std::to_string(g[7] >> 16) + ", iteration " +
+                                   std::to_string((g[6] >> 4) & 3u) + "/" + std::to_string((g[6] >> 8) & 3u) + ", iteration " +
                                    std::to_string((g[7] >> 8) & 0xFFu) + ", colour " + std::to_string(g[7] & 0xFFu) +
                                    ". If other work shares this GPU with phys_update, create the world with PHYS_FLAG_SHARED_GPU").c_str());
     }

@@ -339,7 +339,7 @@ constexpr uint32_t kClusterSlotBytes = 64;  // LDS per body slot: {v, tag} {w, 1
 size_t cluster_lds_bytes(uint32_t slots) { return (size_t)slots * kClusterSlotBytes + (PHYS_MAX_COLORS + 1) * 4 + 12; }
 
 constexpr int kClusterThreads = 256;
-template <bool DIAG>
+template <bool DIAG, bool GUARDED>
 __global__ __launch_bounds__(kClusterThreads, DIAG ? kClusterPerCuDiag : kClusterPerCuFull) void k_solve_cluster(StepCounters* ctr, uint32_t iterations, uint32_t epoch,
                                                                   ClusterRowArrays rows, float friction,
                                                                   const float* __restrict__ inv_inertia, uint32_t inertia_stride,
@@ -353,7 +353,7 @@ __global__ __launch_bounds__(kClusterThreads, DIAG ? kClusterPerCuDiag : kCluste
     float4* s_body = s_lds;
     uint32_t* s_seg = reinterpret_cast<uint32_t*>(s_lds + 4 * (size_t)slots);  // PHYS_MAX_COLORS + 1 row offsets
     if (ctr->overflow) return;
-    if (attempt != 0u && ctr->cluster_state[attempt - 1u] == 1u) return;  // an earlier attempt went through (see below)
+    if (GUARDED && attempt != 0u && ctr->cluster_state[attempt - 1u] == 1u) return;  // an earlier attempt went through (see below)
     const uint32_t cluster = blockIdx.x;
     const uint32_t n_colors = ctr->n_colors;
     const uint32_t etag = epoch << 16;
@@ -390,7 +390,9 @@ __global__ __launch_bounds__(kClusterThreads, DIAG ? kClusterPerCuDiag : kCluste
     // attempt's failure is an error (overflow bit 4).
     // (Counted in after the bodies have been read into LDS - that writes nothing outside the workgroup and overlaps the
     // arrival of the others.)
-    {
+    if (!GUARDED) {
+        __syncthreads();  // the bodies are in LDS
+    } else {
         __shared__ uint32_t s_go;
         if (threadIdx.x == 0) {
             bool solved = false;
@@ -555,7 +557,7 @@ __global__ __launch_bounds__(kClusterThreads, DIAG ? kClusterPerCuDiag : kCluste
                     IA = ld_inertia_c<false>(inv_inertia, h.x * inertia_stride);
                     if (gm.has_b) IB = ld_inertia_c<false>(inv_inertia, h.y * inertia_stride);
                 }
-                uint32_t sweeps = 0;
+                uint32_t sweeps = 0, late = 0;
                 while (needA || needB) {
                     if (needA) {
                         const u32x4c g0 = ld_gran(rv, h.x * 32u), g1 = ld_gran(rv, h.x * 32u + 16u);
@@ -579,18 +581,20 @@ __global__ __launch_bounds__(kClusterThreads, DIAG ? kClusterPerCuDiag : kCluste
                             const bool gone = (wall_clock64() - t_start > timeout_ticks) ||
                                               (__hip_atomic_load(&ctr->overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 16u);
                             if (gone) {
-                                if (atomicCAS(&ctr->debug[0], 0u, 0xC1u) == 0u) {  // the first lane to give up says what it waited for
-                                    const uint32_t ga = needA ? ld_gran(rv, h.x * 32u).w : 0u, gb = needB ? ld_gran(rv, h.y * 32u).w : 0u;
-                                    ctr->debug[1] = cluster | (gridDim.x << 16);
-                                    ctr->debug[2] = d_row; ctr->debug[3] = h.x; ctr->debug[4] = h.y;
-                                    ctr->debug[5] = (tA & 0xFFFFu) | (tB << 16);
-                                    ctr->debug[6] = (needA ? 1u : 0u) | (needB ? 2u : 0u) | (modeA << 4) | (modeB << 8) | ((ga & 0xFFFFu) << 16);
-                                    ctr->debug[7] = (col & 0xFFu) | ((it & 0xFFu) << 8) | ((gb & 0xFFFFu) << 16);
-                                }
+                                late = (needA ? 1u : 0u) | (needB ? 2u : 0u);
                                 flag_overflow(ctr, 16u); dead = true; needA = false; needB = false;
                             }
                         }
                     }
+                }
+                if (late && atomicCAS(&ctr->debug[0], 0u, 0xC1u) == 0u) {
+                    // the first lane to give up says what it waited for (outside the poll loop, and without reading the granules again:
+                    // cold code in the row path costs the whole kernel 1-2 % at its register limit)
+                    ctr->debug[1] = cluster | (gridDim.x << 16);
+                    ctr->debug[2] = d_row; ctr->debug[3] = h.x; ctr->debug[4] = h.y;
+                    ctr->debug[5] = (tA & 0xFFFFu) | (tB << 16);
+                    ctr->debug[6] = late | (modeA << 4) | (modeB << 8);
+                    ctr->debug[7] = (col & 0xFFu) | ((it & 0xFFu) << 8);
                 }
                 if (!dead) {
                     if (!(ablate & 2u)) solve_manifold_geo(&gm, it == 0u || (ablate & 32u), friction, xA, ima, &IA, xB, imb, &IB, &vA, &wA, &vB, &wB);
@@ -651,12 +655,14 @@ void launch_solve_cluster(phys_world* w, void* row_all, uint64_t cap, float fric
     ClusterRowArrays rows;
     rows.all = (float4*)row_all; rows.cap = cap;
     const size_t lds = cluster_lds_bytes(w->cluster_slots);
-    static bool attr_set[2] = {false, false};
-    if (!attr_set[diag ? 1 : 0]) {  // more than the default 64 KiB of dynamic LDS needs the attribute (once per kernel)
-        if (diag) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_solve_cluster<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        else (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_solve_cluster<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    static bool attr_set = false;
+    if (!attr_set) {  // more than the default 64 KiB of dynamic LDS needs the attribute (once per kernel)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_solve_cluster<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_solve_cluster<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_solve_cluster<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_solve_cluster<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipGetLastError();
-        attr_set[diag ? 1 : 0] = true;
+        attr_set = true;
     }
     const dim3 g(w->cluster_count), b(kClusterThreads);
     // Every workgroup of this launch must be resident at once, which the grid size guarantees only if no OTHER launch of
@@ -680,14 +686,17 @@ void launch_solve_cluster(phys_world* w, void* row_all, uint64_t cap, float fric
         const uint32_t last = attempt + 1 == kAttempts ? 1u : 0u;
         // 100 MHz ticks: 0.5 ms, then 20 ms for the workgroups to come in (alone on the device they need ~10 us); < 0: no count
         const long long arrive_ticks = !guarded ? -1ll : (attempt == 0 ? 50000ll : 2000000ll);
-        if (diag)
-            hipLaunchKernelGGL(k_solve_cluster<true>, g, b, lds, w->stream, w->counters.p, w->cfg.solver_iterations, w->flow_epoch, rows,
-                               friction, inertia, stride, w->vel.p, w->pos.p, w->flow_vel.p, (uint32_t)w->n, w->cluster_body.p,
-                               w->body_shared.p, w->seg_start.p, w->cluster_slots, timeout_ticks, ablate, attempt, last, arrive_ticks);
-        else
-            hipLaunchKernelGGL(k_solve_cluster<false>, g, b, lds, w->stream, w->counters.p, w->cfg.solver_iterations, w->flow_epoch, rows,
-                               friction, inertia, stride, w->vel.p, w->pos.p, w->flow_vel.p, (uint32_t)w->n, w->cluster_body.p,
-                               w->body_shared.p, w->seg_start.p, w->cluster_slots, timeout_ticks, ablate, attempt, last, arrive_ticks);
+#define PHYS_CLUSTER_ARGS g, b, lds, w->stream, w->counters.p, w->cfg.solver_iterations, w->flow_epoch, rows, friction, inertia, stride, \
+                          w->vel.p, w->pos.p, w->flow_vel.p, (uint32_t)w->n, w->cluster_body.p, w->body_shared.p, w->seg_start.p,     \
+                          w->cluster_slots, timeout_ticks, ablate, attempt, last, arrive_ticks
+        if (guarded) {
+            if (diag) hipLaunchKernelGGL((k_solve_cluster<true, true>), PHYS_CLUSTER_ARGS);
+            else hipLaunchKernelGGL((k_solve_cluster<false, true>), PHYS_CLUSTER_ARGS);
+        } else {
+            if (diag) hipLaunchKernelGGL((k_solve_cluster<true, false>), PHYS_CLUSTER_ARGS);
+            else hipLaunchKernelGGL((k_solve_cluster<false, false>), PHYS_CLUSTER_ARGS);
+        }
+#undef PHYS_CLUSTER_ARGS
     }
 }
 
