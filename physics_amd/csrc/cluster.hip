@@ -629,7 +629,13 @@ __global__ __launch_bounds__(kClusterThreads, DIAG ? kClusterPerCuDiag : kCluste
                 }
                 // the lane's next row: 256 further on, or its first one again in the next iteration
                 d += kClusterThreads;
-                if (d >= row_end) { d = row_base + threadIdx.x; ++lit; }
+                if (d >= row_end) {
+                    d = row_base + threadIdx.x; ++lit;
+                    // a cluster with fewer rows than lanes: the next row is the one just solved, and its impulses and
+                    // masses, stored a few instructions ago, are about to be read back - loads are not ordered behind
+                    // stores unless waited for
+                    if (d == d_row) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
                 have = lit < iterations && !dead;
                 if (have) fetch();
             }
