@@ -5,22 +5,27 @@
 // Of that, 7.4 us is the scattered 32-byte gather + write-back of the two body velocity records of every row (whole
 // 128-byte lines move for 32 useful bytes, through memory, 264 times per step), ~5 us is what every dependent launch
 // pays before and after its streaming (launch gap, two dependent round trips to memory, drain), 1.3 us is arithmetic.
-// Only the streaming of the row constants (320 B per row and iteration) is compulsory.
+// Only the streaming of the row constants is compulsory.
 //
-// So: bodies are grouped into spatial clusters (Morton order of their positions at phys_set_bodies, `slots` bodies
-// each, at most one cluster per CU); a workgroup owns one cluster for the whole solve and keeps its bodies' {v, w} in
-// LDS. The rows are sorted by (cluster of body A, colour); per iteration the workgroup walks its colours in ascending
-// order with a workgroup barrier between them - the spec's order of updates per body, as before - and streams its rows
-// from memory exactly once per iteration. A body all of whose rows lie in one cluster never leaves LDS.
+// So: bodies are grouped into spatial clusters - statically (Morton order of the owned bodies' positions at
+// phys_set_bodies) where they all fit the chip's LDS, else dynamically (every few updates, the bodies that have manifolds,
+// in the broad phase's bucket order) - of `slots` bodies each, up to three clusters per CU; a workgroup owns one cluster
+// for the whole solve and keeps its bodies' {v, w, 1/m, x, I^-1 diagonal} in LDS. The rows are sorted by (owner cluster,
+// colour) - a row belongs to the home of its body A, else of its body B; per iteration the workgroup walks its colours in
+// ascending order with a workgroup barrier between them - the spec's order of updates per body, as before - and streams
+// its rows from memory exactly once per iteration, COMPACT (contact points + bias, accumulated impulses, row masses made
+// in iteration 0; lever arms remade from the positions in LDS: solve_manifold_geo) and fetched one or two colour steps
+// ahead. A body all of whose rows lie in one cluster never leaves LDS.
 // A body touched by a row of ANOTHER cluster is `shared`: its updates travel between workgroups through the same
-// data-tagged 16-byte granules as in k_solve_flow (tag = epoch | number of updates applied, sc1 stores / loads; the k-th
-// update of a body may only be made by the row holding ticket k). A shared body of the own cluster is also kept in
-// LDS with its tag, so a chain of updates that stays inside the workgroup never waits for memory; only an update
-// that follows a REMOTE one polls the granule. The first update of a body reads `vel`, the last one writes it.
+// data-tagged 16-byte granules as in k_solve_flow (tag = epoch | number of updates applied, write-through stores, loads
+// past the L2; the k-th update of a body may only be made by the row holding ticket k). A shared body of the own cluster
+// is also kept in LDS with its tag, so a chain of updates that stays inside the workgroup never waits for memory; only an
+// update that follows a REMOTE one polls the granule. The first update of a body reads `vel`, the last one writes it. A
+// body without a home (ghosts; bodies beyond the capacity of dynamic homes) is "another cluster's body" for every row.
 // No deadlock: every workgroup processes its rows in the global (iteration, colour) order, so the earliest unfinished
-// row of the whole solve never waits; all workgroups are resident (grid <= CUs, checked on the host); every spin is
-// bounded (timeout -> overflow bit 4 -> PHYS_ERR_HIP). Same arithmetic (solve_manifold_lazy), same order per body:
-// bit-identical to the other solver paths.
+// row of the whole solve never waits; all workgroups are resident (grid sized on the host; an all-or-nothing start where
+// other streams' work can run beside the launch: see the kernel); every spin is bounded (timeout -> overflow bit 4 ->
+// PHYS_ERR_HIP). Same arithmetic, same order per body: bit-identical to the other solver paths.
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
