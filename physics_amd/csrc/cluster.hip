@@ -592,9 +592,10 @@ __global__ __launch_bounds__(kClusterThreads, DIAG ? kClusterPerCuDiag : kCluste
                         }
                     }
                 }
-                if (late && atomicCAS(&ctr->debug[0], 0u, 0xC1u) == 0u) {
+                if (GUARDED && late && atomicCAS(&ctr->debug[0], 0u, 0xC1u) == 0u) {
                     // the first lane to give up says what it waited for (outside the poll loop, and without reading the granules again:
-                    // cold code in the row path costs the whole kernel 1-2 % at its register limit)
+                    // cold code in the row path costs the whole kernel 1-2 % at its register limit - so only in the guarded variant,
+                    // where a time-out is a defect; in the other one it means the GPU was shared without PHYS_FLAG_SHARED_GPU)
                     ctr->debug[1] = cluster | (gridDim.x << 16);
                     ctr->debug[2] = d_row; ctr->debug[3] = h.x; ctr->debug[4] = h.y;
                     ctr->debug[5] = (tA & 0xFFFFu) | (tB << 16);
