@@ -268,3 +268,26 @@ def test_rccl_exchange_behind_the_c_abi_with_one_rank():
         comm.close()
     assert st.n_manifolds > 0
     w.close()
+
+
+def test_rccl_exchange_of_aabb_records_with_one_rank():
+    """The broad-phase-only form of the exchange (no ghost slots: 32-byte AABB records, phys_halo_pack / phys_halo_pairs
+    around the collective) through phys_halo_exchange, in both topologies, with a one-rank communicator: the collective
+    completes on the world's stream, nothing comes back (a rank has no cross pairs with itself)."""
+    import physics_amd
+    from physics_amd import scenes
+    sc = scenes.c4(20, 20, 20)
+    w = physics_amd.World(sc.config())
+    sc.populate(w)
+    w.set_global_ids(np.arange(sc.n, dtype=np.uint32))
+    w.set_slab(float(sc.pos[:, 0].min()) - 1.0, float(sc.pos[:, 0].max()) + 1.0, 3.0)  # the outermost layers are boundary bodies
+    for neighbours in (False, True):
+        comm = physics_amd.Comm(w, physics_amd.Comm.unique_id(), 0, 1, 8192, neighbours=neighbours)
+        for _ in range(3):
+            w.update(DT)
+            w.halo_exchange(comm)
+        w.sync()
+        st = w.get_stats()
+        assert st.overflow == 0 and st.n_cross_pairs == 0 and st.n_pairs > 0
+        comm.close()
+    w.close()
