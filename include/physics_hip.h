@@ -59,6 +59,11 @@ extern "C" {
                                             tried again): ~0.06 ms per update. Implied when the process holds several
                                             worlds on one device. Same results either way. */
 
+#define PHYS_FLAG_SOLVER_CLUSTER 0x40u    /* contact solver: the cluster kernel (body velocities resident in LDS per spatial
+                                            cluster, one launch) wherever the scene admits it (>= 32768 bodies, > 40k
+                                            manifolds), instead of only where it is the fastest path (>= 200k manifolds).
+                                            Bit-identical results; for tests and measurements */
+
 typedef struct phys_config {
     uint32_t abi_version;       /* PHYS_ABI_VERSION */
     int32_t device;             /* HIP device ordinal */
@@ -94,7 +99,8 @@ typedef struct phys_stats {
     int32_t cg_converged;   /* 1 = Some(lambda), 0 = None (sle_solver.rs:45) */
     uint64_t steps;         /* updates since creation */
     uint32_t overflow;      /* bit 0 pairs, 1 manifolds, 2 colours (> 64 manifolds at one body), 3 halo / cross pairs,
-                               4 solver hand-off timeout: the last update's bits OR every bit raised since the last phys_sync */
+                               4 solver hand-off timeout, 6 colour table full: the last update's bits OR every bit raised since
+                               the last phys_sync */
     uint32_t n_ground_manifolds; /* manifolds against the ground plane (subset of n_manifolds) */
     float max_extent;       /* largest fattened-AABB edge of the last broad phase (the grid cell is 1.001x this) */
     uint32_t n_halo_records; /* records written by the last phys_halo_pack */

@@ -159,9 +159,8 @@ void CollisionWorld::narrowphase(const std::vector<RigidBody>& bodies) {
 
 // Colouring of one step (include/spec/contact_solve.h "persistent colouring"): a manifold that existed in
 // the previous update keeps its colour; only the new ones go through the Jones-Plassmann rounds, against
-// `used` masks pre-seeded with the kept colours. Every PHYS_COLOR_CACHE_PERIOD-th update (counted from
-// phys_set_bodies) nothing is kept. `persistent = false` (the collide_now test hook) neither reads nor updates
-// the cache.
+// `used` masks pre-seeded with the kept colours (never re-compacted: contact_solve.h). `persistent = false` (the
+// collide_now test hook) neither reads nor updates the cache.
 void CollisionWorld::color_manifolds(size_t n_bodies, bool persistent) {
     const size_t M = manifolds.size();
     const uint32_t UNCOLORED = 0xFFFFFFFFu;
@@ -171,7 +170,7 @@ void CollisionWorld::color_manifolds(size_t n_bodies, bool persistent) {
     size_t remaining = M;
     n_colors = 0;
     color_rounds = 0;
-    const bool keep = persistent && (color_epoch % PHYS_COLOR_CACHE_PERIOD) != 0;
+    const bool keep = persistent;  // the cache of the first update is empty
     if (keep) {
         for (size_t m = 0; m < M; ++m) {
             const Manifold& mf = manifolds[m];

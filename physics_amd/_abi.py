@@ -20,6 +20,7 @@ SHAPE_NONE, SHAPE_SPHERE, SHAPE_BOX = 0, 1, 2
 FLAG_COLLISIONS, FLAG_GROUND_PLANE, FLAG_EXACT_ROTATION, FLAG_BROADPHASE_ONLY = 1, 2, 4, 8
 FLAG_SOLVER_PER_COLOR = 16
 FLAG_SHARED_GPU = 32
+FLAG_SOLVER_CLUSTER = 64
 GROUND_ID = 0xFFFFFFFF
 
 f32p = C.POINTER(C.c_float)

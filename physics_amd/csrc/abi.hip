@@ -449,6 +449,9 @@ int32_t phys_sync(phys_world* w) {
                                        "that step was skipped. This limit is not configurable");
     if (bits & 8u)
         return fail(PHYS_ERR_CAPACITY, "halo record / cross-pair capacity exceeded in a step since the last phys_sync");
+    if (bits & 64u)
+        return fail(PHYS_ERR_CAPACITY, "the persistent colour table is full (a look-up or an insert gave up after thousands of "
+                                       "slots): the contact solve of that step was skipped. Raise phys_config.max_manifolds");
     if (bits)
         return fail(PHYS_ERR_CAPACITY, "pair / manifold capacity exceeded in a step since the last phys_sync (the contact "
                                        "solve of that step was skipped): raise phys_config.max_pairs / max_manifolds");

@@ -563,6 +563,9 @@ int32_t collision_alloc(phys_world* w) {
         {
             uint64_t cap = 4096;
             while (cap < M + M / 2) cap <<= 1;
+            // PHYS_DEBUG_CTAB_SLOTS=<power of two>: a smaller table (tests of the bounded walks: crowded and overfull tables)
+            static const uint64_t slots_env = getenv("PHYS_DEBUG_CTAB_SLOTS") ? strtoull(getenv("PHYS_DEBUG_CTAB_SLOTS"), nullptr, 10) : 0;
+            if (slots_env >= 64 && (slots_env & (slots_env - 1)) == 0) cap = slots_env;
             PHYS_HIP_TRY(w->ctab.resize(2 * cap));
             w->ctab_mask = (uint32_t)(cap - 1);
             w->ctab_valid = false;
@@ -584,7 +587,9 @@ int32_t collision_alloc(phys_world* w) {
             // tags of an earlier scene must never look like tags of this one
             PHYS_HIP_TRY(hipMemsetAsync(w->flow_vel.p, 0, 8 * n * sizeof(float), w->stream));
             PHYS_HIP_TRY(hipMemsetAsync(w->row_acc.p, 0, 16 * M * sizeof(float), w->stream));
-            w->flow_epoch = 0;
+            // PHYS_DEBUG_FLOW_EPOCH=<n>: start the tag epoch near its wrap (test of the 16-bit epoch reset)
+            static const uint32_t epoch_env = getenv("PHYS_DEBUG_FLOW_EPOCH") ? (uint32_t)strtoul(getenv("PHYS_DEBUG_FLOW_EPOCH"), nullptr, 0) : 0u;
+            w->flow_epoch = epoch_env;
         }
     }
     return PHYS_OK;

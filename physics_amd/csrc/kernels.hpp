@@ -78,7 +78,9 @@ __device__ __forceinline__ m33 ld_inertia_c(const float* __restrict__ p, uint32_
 //   * a key's live entry is always the first entry of that key in its chain (a dead one before it would have been
 //     reused by the insert), chains never shrink (slots go back to empty only in the reset), so a probe may stop at the
 //     first empty slot or the first entry with its key.
-//   * every PHYS_COLOR_CACHE_PERIOD-th update (nothing is kept then anyway) the table is reset by one memset.
+//   * every PHYS_COLOR_CACHE_PERIOD-th update the table is REBUILT: emptied by one memset behind the narrow phase (which has
+//     taken the kept colours from it by then) and refilled by k_rows_build with every manifold of that update. No colour
+//     changes; the dead entries of the period are gone.
 // Round 1-2a rebuilt a table per update inside k_rows_build (an atomic and two scattered stores per manifold, plus the
 // sparse clear of the other table): 0.26 of k_rows_build's 0.50 ms on C5. The layout depends on arrival order, the
 // answers (exact key + stamp matches) do not.
@@ -87,15 +89,18 @@ struct ColorTableJob {
     ulonglong2* tab;  // null: nothing to do
     uint32_t mask;
     uint32_t stamp;   // of the update whose manifolds are being inserted
+    uint32_t all;     // != 0: table rebuild - the manifolds that kept their colour are inserted too
     const uint32_t* man_color; const uint64_t* man_prio;
 };
 
-__device__ __forceinline__ void color_table_insert(const ColorTableJob& job, uint32_t a, uint32_t b, uint32_t m) {
+__device__ __forceinline__ void color_table_insert(const ColorTableJob& job, uint32_t a, uint32_t b, uint32_t m, StepCounters* ctr) {
     const unsigned long long key = ((unsigned long long)a << 32) | b;
     const unsigned long long val = ((unsigned long long)job.stamp << 32) | job.man_color[m];
     uint32_t h = (uint32_t)(job.man_prio[m] >> 20) & job.mask;
-    // bounded (see the walk in k_narrowphase): a manifold that finds no slot is simply coloured afresh next time
-    for (uint32_t walked = 0; walked < 4u * kColorTableMaxWalk; ++walked) {
+    // bounded (see the walk in k_narrowphase); a manifold that finds no slot would be coloured afresh next time where the
+    // oracle keeps its colour: the update is flagged (bit 6), never a silent divergence
+    for (uint32_t walked = 0; ; ++walked) {
+        if (walked == 4u * kColorTableMaxWalk) { flag_overflow(ctr, 64u); return; }
         unsigned long long* vp = &job.tab[h].y;
         const unsigned long long seen = __hip_atomic_load(vp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if ((uint32_t)(seen >> 32) != job.stamp && atomicCAS(vp, seen, val) == seen) {

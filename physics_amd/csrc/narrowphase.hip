@@ -115,9 +115,9 @@ __global__ __launch_bounds__(kNpThreads) void k_narrowphase(
             if (cache_mask) {
                 const unsigned long long key = ((unsigned long long)a << 32) | b;
                 uint32_t h = (uint32_t)(prio >> 20) & cache_mask;
-                // bounded walk: the table is reset every PHYS_COLOR_CACHE_PERIOD updates and holds 1.5 slots per manifold
+                // bounded walk: the table is rebuilt every PHYS_COLOR_CACHE_PERIOD updates and holds 1.5 slots per manifold
                 // slot, but a chain of live and dead entries without an empty slot must end the walk, not hang the GPU
-                // (a pair given up on is coloured afresh: still a proper colouring)
+                bool ended = false;
                 for (uint32_t walked = 0; walked < kColorTableMaxWalk; ++walked) {
                     const ulonglong2 e = (have_early && h == early_h) ? early : cache[h];
                     have_early = false;
@@ -126,11 +126,15 @@ __global__ __launch_bounds__(kNpThreads) void k_narrowphase(
                             col = (uint32_t)e.y;
                             cache[h].y = ((unsigned long long)stamp << 32) | col;
                         }
+                        ended = true;
                         break;  // a dead entry of this key: no live one follows
                     }
-                    if (e.x == ~0ull) break;  // empty slot: never seen
+                    if (e.x == ~0ull) { ended = true; break; }  // empty slot: never seen
                     h = (h + 1) & cache_mask;
                 }
+                // a walk given up on might have passed over a colour the oracle's map keeps: never silently (bit 6: the
+                // update is flagged and its solve skipped, like any other capacity miss)
+                if (!ended) flag_overflow(ctr, 64u);
             }
             if (col != kUncolored) {
                 bit = 1ull << col;
@@ -708,8 +712,8 @@ void launch_narrowphase(phys_world* w) {
     const uint64_t work = (uint64_t)n_ground + w->max_pairs;
     // colouring state of the step: used masks + three rotating priority buffers (one memset); the narrow
     // phase publishes round 0's per-body maxima as it emits manifolds
-    // persistent colouring: colours of the previous update are kept, unless this is a re-compaction update
-    const uint32_t cache_mask = (w->color_epoch % PHYS_COLOR_CACHE_PERIOD) != 0 && w->ctab_valid ? w->ctab_mask : 0u;
+    // persistent colouring: colours of the previous update are kept (contact_solve.h)
+    const uint32_t cache_mask = w->ctab_valid ? w->ctab_mask : 0u;
     const uint32_t stamp = (uint32_t)w->color_epoch + 1u;  // never 0xFFFFFFFF (the stamp of an empty slot) in a world's life
     PHYS_PROF(w, PHYS_STAGE_NARROW);
 #define PHYS_NP_LAUNCH(T)                                                                                              \
@@ -757,8 +761,12 @@ void launch_coloring(phys_world* w) {
     }
     const unsigned blocks = (unsigned)blocks64;
     uint32_t rounds = 0;
-    // a full re-colouring (every PHYS_COLOR_CACHE_PERIOD-th update) needs far more rounds than an incremental one
-    const bool full = ((w->color_epoch % PHYS_COLOR_CACHE_PERIOD) == 0) || !w->ctab_valid;
+    // a full colouring (the first update after phys_set_bodies: nothing to keep) needs far more rounds than an incremental one
+    const bool full = !w->ctab_valid;
+    // every PHYS_COLOR_CACHE_PERIOD-th update the colour TABLE is rebuilt: emptied here - the narrow phase of this update
+    // has taken what it keeps from it already - and refilled by k_rows_build with every manifold of this update instead of
+    // the new ones only. That purges the dead entries (chains never shrink otherwise) and changes no colour.
+    const bool rebuild = full || (w->color_epoch % PHYS_COLOR_CACHE_PERIOD) == 0;
     w->snap_tag_full = full;
     const bool known = w->hint.valid && (!full || w->hint.full_rounds > 0);
     const bool small = w->hint.valid && w->hint.n_manifolds <= (uint32_t)(kSmallTrips * kColorThreads);
@@ -766,12 +774,13 @@ void launch_coloring(phys_world* w) {
     // cluster solver this update? (decided here because it decides the ORDER of the rows: by (cluster, colour)
     // instead of by colour). PHYS_DEBUG_CLUSTER_MIN=<manifolds> moves the threshold (measurements; same bits either way).
     static const char* cluster_min_env = getenv("PHYS_DEBUG_CLUSTER_MIN");
-    const uint64_t cluster_min = cluster_min_env ? strtoull(cluster_min_env, nullptr, 10) : kClusterMinManifolds;
+    const bool cluster_forced = (w->cfg.flags & PHYS_FLAG_SOLVER_CLUSTER) != 0u;
+    const uint64_t cluster_min = cluster_forced ? 0 : (cluster_min_env ? strtoull(cluster_min_env, nullptr, 10) : kClusterMinManifolds);
     // worth it where contacts are dense (C5: 11 rows per body): velocities stay in LDS for many rows each. Sparse piles
     // (the 1M-cube scene: 0.4-0.5 rows per body, contacts in the bottom layers only) leave most clusters idle and a few
     // overloaded - they keep the dataflow / per-colour kernels, which spread rows evenly over the chip
     // (dynamic clusters hold only the bodies that have manifolds: nothing idles, the row count alone decides)
-    const bool dense = cluster_min_env || w->cluster_dynamic || 2ull * w->hint.n_manifolds >= 3ull * w->n_owned;
+    const bool dense = cluster_forced || cluster_min_env || w->cluster_dynamic || 2ull * w->hint.n_manifolds >= 3ull * w->n_owned;
     w->cluster_step = (w->cluster_count > 0 || w->cluster_dynamic) && w->hint.valid && !small && dense &&
                       w->hint.n_manifolds >= cluster_min && !(w->cfg.flags & PHYS_FLAG_SOLVER_PER_COLOR) &&
                       w->cfg.solver_iterations > 0 && w->cfg.solver_iterations < 1000 && w->hint.n_colors > 0;
@@ -825,11 +834,12 @@ void launch_coloring(phys_world* w) {
     }
     {
         // the new manifolds of this update go into the colour table in k_rows_build (launch_solver): one launch less
-        if (full) {  // nothing was kept: start from an empty table (this also purges the dead entries of the period)
+        if (rebuild) {  // start from an empty table: every manifold of this update is inserted
             PHYS_PROF(w, PHYS_STAGE_ROWS);
             (void)hipMemsetAsync(w->ctab.p, 0xFF, ((size_t)w->ctab_mask + 1) * 16, s);
         }
         w->ctab_job_pending = true;
+        w->ctab_job_all = rebuild;
         w->ctab_job_stamp = (uint32_t)w->color_epoch + 1u;
         w->ctab_valid = true;
         w->color_epoch++;

@@ -60,7 +60,7 @@ struct RowArrays {
 };
 
 template <bool DIAG>
-__global__ __launch_bounds__(256) void k_rows_build(const StepCounters* __restrict__ ctr, RowArrays rows, solve_params_t sp,
+__global__ __launch_bounds__(256) void k_rows_build(StepCounters* __restrict__ ctr, RowArrays rows, solve_params_t sp,
                                                     const uint32_t* __restrict__ row_src,
                                                     const float* __restrict__ man_geo /* 128-byte records */,
                                                     const float* __restrict__ pos,
@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void k_rows_build(const StepCounters* __restri
         }
         const int has_b = b != PHYS_GROUND_ID;
         // persistent colouring: a manifold that is new in this update enters the colour table (kernels.hpp)
-        if (table.tab && __float_as_uint(r0.w) == 0u) color_table_insert(table, a, b, m);
+        if (table.tab && (table.all || __float_as_uint(r0.w) == 0u)) color_table_insert(table, a, b, m, ctr);
         uint32_t ticket = 0;
         if (flow) {
             // the colours in use at a body are exactly the colours of its manifolds (all distinct), so the rank of
@@ -1033,8 +1033,18 @@ void launch_solver(phys_world* w, float dt) {
         table.tab = reinterpret_cast<ulonglong2*>(w->ctab.p);
         table.mask = w->ctab_mask;
         table.stamp = w->ctab_job_stamp;
+        table.all = w->ctab_job_all ? 1u : 0u;
         table.man_color = w->man_color.p; table.man_prio = w->man_prio.p;
         w->ctab_job_pending = false;
+    }
+    if (flow && ++w->flow_epoch > 0xFFFFu) {
+        // tags would repeat: forget every old one. AHEAD of k_rows_build: on a cluster step that kernel writes the constants
+        // of foreign bodies into planes 12-15 = row_acc (with flow != 0 it never writes the impulses there), and a memset
+        // behind it wiped them - every 65535th solve ran with x = 0, 1/m = 0, I^-1 = 0 for those rows
+        PHYS_PROF(w, PHYS_STAGE_MISC);
+        (void)hipMemsetAsync(w->flow_vel.p, 0, 8 * w->n * sizeof(float), s);
+        (void)hipMemsetAsync(w->row_acc.p, 0, 16 * cap * sizeof(float), s);
+        w->flow_epoch = 1;
     }
     { PHYS_PROF(w, PHYS_STAGE_ROWS);
       if (diag)
@@ -1048,11 +1058,6 @@ void launch_solver(phys_world* w, float dt) {
                              w->color_state.p, flow ? (stall ? 2 : 1) : 0, table, w->cluster_slot.p, w->body_shared.p,
                              w->cluster_step ? w->cluster_slots : 0u, w->cluster_count); }
     if (flow) {
-        if (++w->flow_epoch > 0xFFFFu) {  // tags would repeat: forget every old one
-            (void)hipMemsetAsync(w->flow_vel.p, 0, 8 * w->n * sizeof(float), s);
-            (void)hipMemsetAsync(w->row_acc.p, 0, 16 * cap * sizeof(float), s);
-            w->flow_epoch = 1;
-        }
         if (cluster) {
             PHYS_PROF(w, PHYS_STAGE_SOLVE_CLUSTER);
             launch_solve_cluster(w, rows.all, cap, sp.friction, inertia, stride, diag, timeout_ticks);

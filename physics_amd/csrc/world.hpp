@@ -67,7 +67,7 @@ struct StepCounters {
     uint32_t n_uncolored;    // manifolds still uncoloured (colouring loop)
     uint32_t n_colors;       // colours in use
     uint32_t color_rounds;
-    uint32_t overflow;       // bit 0 pairs, bit 1 manifolds, bit 2 colours, bit 3 cross pairs, bit 4 solver hand-off timeout, bit 5 corrupt solver row refused
+    uint32_t overflow;       // bit 0 pairs, bit 1 manifolds, bit 2 colours, bit 3 cross pairs, bit 4 solver hand-off timeout, bit 5 corrupt solver row refused, bit 6 colour table walk given up
     uint32_t n_halo;         // halo records packed
     uint32_t n_cross_pairs;
     uint32_t n_ground_manifolds;
@@ -232,6 +232,7 @@ struct phys_world {
     uint64_t color_epoch = 0;   // updates with collisions since phys_set_bodies
     bool ctab_job_pending = false;  // launch_coloring prepared a table build for launch_solver's k_rows_build
     uint32_t ctab_job_stamp = 0;    // the stamp its entries get
+    bool ctab_job_all = false;      // table rebuild: every manifold of the update is inserted, not only the new ones
     phys::DevBuf<uint32_t> color_block_hist;  // [colour][workgroup] histogram / offsets of the colour sort
     // colouring state
     phys::DevBuf<unsigned long long> color_state;  // 4n: used masks | three rotating per-body priority buffers

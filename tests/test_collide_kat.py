@@ -132,6 +132,48 @@ def test_box_box_face_contact_and_sphere_box():
     assert np.allclose(points[0, 0, :3], [0.3, 1.0, -0.2], atol=1e-6)
 
 
+@pytest.mark.parametrize("offset,expect", [
+    ((2.0, 0.0, 0.0), 4),    # face neighbour, touching: full 2 x 2 patch at depth 0 - a contact
+    ((2.0, 2.0, 0.0), 0),    # edge-diagonal neighbour: the patch is a line - a sliver, not a contact
+    ((2.0, 2.0, 2.0), 0),    # corner-diagonal neighbour: the patch is a point
+    ((2.0, 1.95, 0.0), 0),   # patch 0.05 wide (< 0.1 x half extent 1), depth 0: still a sliver
+    ((2.0, 1.8, 0.0), 4),    # patch 0.2 wide: a contact, whatever its depth
+    ((1.99, 1.95, 0.0), 4),  # a sliver again, but it penetrates by 0.01 > margin / 4: kept
+    ((1.996, 1.95, 0.0), 0),  # penetrates by 0.004 <= margin / 4: dropped
+])
+def test_sliver_rule_of_the_box_face_contact(offset, expect):
+    """collide.h box_face_contact: a face contact whose patch is narrower than 0.1 x the smallest half extent of the
+    two faces and whose deepest point penetrates by no more than a quarter of the margin is not a contact."""
+    w = world()
+    st, he = boxes(2)
+    w.set_bodies(np.array([[0, 0, 0], offset], np.float32), shape_type=st, half_extent=he)
+    w.collide_now()
+    ids, cnt, nrm, pts = w.get_manifolds()
+    if expect == 0:
+        assert len(ids) == 0
+        return
+    assert len(ids) == 1 and cnt[0] == expect
+    assert np.allclose(np.abs(nrm[0]), (1, 0, 0), atol=1e-6)
+    assert np.allclose(pts[0, :, 3], 2.0 - offset[0], atol=1e-5)
+
+
+def test_tilted_edge_resting_on_a_face_is_not_a_sliver():
+    """A box tilted by 20 degrees about z, its lower edge 0.002 deep in the top face of another: a LINE contact (two
+    points), but its patch - the incident face inside the reference face's side planes, before the depth filter - is as
+    wide as the face, so the sliver rule leaves it alone."""
+    w = world()
+    st, he = boxes(2)
+    ang = np.deg2rad(20.0)
+    q = np.array([0, 0, np.sin(ang / 2), np.cos(ang / 2)], np.float32)
+    low = np.cos(ang) + np.sin(ang)  # lowest corner below the centre of the tilted unit cube
+    pos = np.array([[0, 0, 0], [0.3, 1.0 + low - 0.002, 0.0]], np.float32)
+    w.set_bodies(pos, rot=np.stack([[0, 0, 0, 1], q]).astype(np.float32), shape_type=st, half_extent=he)
+    w.collide_now()
+    ids, cnt, nrm, pts = w.get_manifolds()
+    assert len(ids) == 1 and cnt[0] == 2
+    assert np.allclose(pts[0, :2, 3], 0.002, atol=2e-5)
+
+
 def test_box_box_edge_edge_contact():
     w = world()
     st, he = boxes(2)

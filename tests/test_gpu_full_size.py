@@ -87,8 +87,12 @@ def test_c5_256k_tower_properties():
     runs = []
     for r in range(2):
         w = _world(sc)
-        w.update_n(DT, 40)
+        w.update_n(DT, 36)
+        w.profile_enable(True)
+        w.update_n(DT, 4)
         w.sync()
+        assert "solve_cluster" in w.profile_get()[0], "C5 is the cluster solver's scene"
+        w.profile_enable(False)
         st = w.get_stats()
         runs.append(w.get_transforms() + w.get_velocities() + (np.array([st.n_pairs, st.n_manifolds, st.n_contacts, st.n_colors]),))
         if r == 0:

@@ -1,0 +1,104 @@
+"""GPU: bit parity with the CPU oracle AT THE SIZES THE BENCH CLAIMS. The oracle needs seconds per
+step at these sizes (OpenMP over its independent loops; same bits for any thread count), so the scene is first advanced
+on the GPU to the state the bench times, that state is downloaded, and a FRESH HIP world and an oracle world are both
+seeded with it and stepped three times side by side: poses, velocities and counters must agree in every bit, and the
+solver path the bench line is quoted on (k_solve_cluster) must be the one that ran. A fresh world has no launch-size
+hint for its first update (per-colour launches), so the cluster kernel solves updates two and three."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+DT = 16_666_667
+
+
+def _advance_on_gpu(sc, steps):
+    import physics_amd
+    w = physics_amd.World(sc.config())
+    sc.populate(w)
+    w.update_n(DT, steps)
+    w.sync()
+    st = w.get_stats()
+    state = w.get_transforms() + w.get_velocities()
+    w.close()
+    return state, st
+
+
+def _seeded_pair(sc, state, flags_extra=0):
+    import physics_amd
+    from oracle import binding as ob
+    pos, rot, lin, ang = state
+    w = physics_amd.World(sc.config(flags=sc.flags | flags_extra))
+    o = ob.OracleWorld(sc.config(), trig=ob.TRIG_DET)
+    o.set_threads(min(len(os.sched_getaffinity(0)), 16))
+    for x in (w, o):
+        x.set_bodies(pos, rot=rot, lin_vel=lin, ang_vel=ang, shape_type=sc.shape_type, half_extent=sc.half_extent)
+    return w, o
+
+
+def _three_steps_side_by_side(sc, pre, min_manifolds, flags_extra=0):
+    state, st0 = _advance_on_gpu(sc, pre)
+    assert st0.overflow == 0 and st0.n_manifolds >= min_manifolds, (st0.n_manifolds, st0.overflow)
+    w, o = _seeded_pair(sc, state, flags_extra)
+    w.profile_enable(True)
+    for step in range(3):
+        w.update(DT)
+        o.update(DT)
+        w.sync()
+        for name, a, b in zip(("pos", "rot", "lin", "ang"), w.get_transforms() + w.get_velocities(),
+                              o.get_transforms() + o.get_velocities()):
+            assert np.array_equal(a, b), f"{sc.name} step {pre}+{step + 1}: {name} differs from the oracle (max {np.abs(a - b).max()})"
+        sw, so = w.get_stats(), o.get_stats()
+        for f in ("n_pairs", "n_manifolds", "n_contacts", "n_colors", "color_rounds"):
+            assert getattr(sw, f) == getattr(so, f), (f, getattr(sw, f), getattr(so, f))
+    prof, _ = w.profile_get()
+    assert "solve_cluster" in prof and prof["solve_cluster"][1] == 2, f"cluster solver launches: {prof}"
+    n = w.get_stats().n_manifolds
+    w.close()
+    o.close()
+    return n
+
+
+def test_c5_256k_tower_three_steps_equal_the_oracle():
+    """C5 = the bench headline: 256 000 boxes, state after 35 updates (the start of the bench's timed window), static
+    clusters of the cluster solver."""
+    from physics_amd import scenes
+    assert _three_steps_side_by_side(scenes.c5(), 35, 600_000) >= 600_000
+
+
+def test_t1m_1m_cubes_three_steps_equal_the_oracle():
+    """The north_star scene: 1M cubes, state after 105 updates (>= 300k manifolds in the bottom third of the pile):
+    DYNAMIC homes of the cluster solver, dealt out on the device."""
+    from physics_amd import scenes
+    assert _three_steps_side_by_side(scenes.target_1m(), 105, 300_000) >= 300_000
+
+
+def test_c3_100k_mixed_three_steps_equal_the_oracle():
+    """C3: 100 000 mixed spheres / cubes after 155 updates, cluster solver asked for (the scene sits at its threshold)."""
+    import physics_amd
+    from physics_amd import scenes
+    assert _three_steps_side_by_side(scenes.c3(), 155, 150_000, physics_amd.FLAG_SOLVER_CLUSTER) >= 150_000
+
+
+def test_c5_full_size_cluster_solver_equals_the_per_colour_kernels_over_40_steps():
+    """tools/ab_solver.py's hash compare as a test: the default path (cluster solver from the second update on) against
+    one launch per colour (PHYS_FLAG_SOLVER_PER_COLOR) on the full 256k tower, 40 updates from the initial scene."""
+    import physics_amd
+    from physics_amd import scenes
+    sc = scenes.c5()
+    out = []
+    for extra in (0, physics_amd.FLAG_SOLVER_PER_COLOR):
+        w = physics_amd.World(sc.config(flags=sc.flags | extra))
+        sc.populate(w)
+        w.update_n(DT, 36)
+        w.profile_enable(True)
+        w.update_n(DT, 4)
+        w.sync()
+        prof, _ = w.profile_get()
+        assert ("solve_cluster" in prof) == (extra == 0), sorted(prof)
+        st = w.get_stats()
+        out.append(w.get_transforms() + w.get_velocities() + (np.array([st.n_pairs, st.n_manifolds, st.n_contacts, st.n_colors]),))
+        w.close()
+    for a, b in zip(out[0], out[1]):
+        assert np.array_equal(a, b)

@@ -186,7 +186,7 @@ def test_cluster_solver_with_ghosts_equals_the_per_colour_kernels():
         worlds, sends = [], []
         cap = 8192
         for r in range(2):
-            cfg = sc.config(flags=sc.flags | flags_extra, max_ghosts=2 * cap)
+            cfg = sc.config(flags=sc.flags | (flags_extra or physics_amd.FLAG_SOLVER_CLUSTER), max_ghosts=2 * cap)
             w = physics_amd.World(cfg)
             pos = sc.pos.copy()
             pos[:, 0] += np.float32(r * width)

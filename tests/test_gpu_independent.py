@@ -72,6 +72,63 @@ def outside_distance(p, c, R, h):
     return float(np.max(np.abs((p - c) @ R) - h))
 
 
+def face_patch(cR, RR, hR, axis, n_ref, cI, RI, hI):
+    """The contact patch of a face contact, in float64 and written for this file: the face of the incident box most
+    anti-parallel to n_ref, clipped (Sutherland-Hodgman) to the four side planes of the reference face. Returns
+    (patch width = the smaller extent along the reference face's two in-plane axes, the smallest half extent of the
+    two faces, deepest point below the reference face) - the three numbers of collide.h's sliver rule - or None when
+    nothing is left of the incident face."""
+    dots = n_ref @ RI
+    j = int(np.argmax(np.abs(dots)))
+    jsgn = -1.0 if dots[j] > 0 else 1.0
+    j1, j2 = (j + 1) % 3, (j + 2) % 3
+    fc = cI + RI[:, j] * jsgn * hI[j]
+    e1, e2 = RI[:, j1] * hI[j1], RI[:, j2] * hI[j2]
+    poly = [fc + e1 + e2, fc - e1 + e2, fc - e1 - e2, fc + e1 - e2]
+    r1, r2 = (axis + 1) % 3, (axis + 2) % 3
+    for u, lim in ((RR[:, r1], hR[r1]), (-RR[:, r1], hR[r1]), (RR[:, r2], hR[r2]), (-RR[:, r2], hR[r2])):
+        out = []
+        for k in range(len(poly)):
+            a, b = poly[k], poly[(k + 1) % len(poly)]
+            da, db = (a - cR) @ u - lim, (b - cR) @ u - lim
+            if da <= 0:
+                out.append(a)
+                if db > 0:
+                    out.append(a + (b - a) * (da / (da - db)))
+            elif db <= 0:
+                out.append(a + (b - a) * (da / (da - db)))
+        poly = out
+        if not poly:
+            return None
+    P = np.array(poly)
+    c1, c2 = (P - cR) @ RR[:, r1], (P - cR) @ RR[:, r2]
+    width = min(c1.max() - c1.min(), c2.max() - c2.min())
+    face = min(hR[r1], hR[r2], hI[j1], hI[j2])
+    deepest = float(np.max(hR[axis] - (P - cR) @ n_ref))
+    return float(width), float(face), deepest
+
+
+SLIVER_REL, SLIVER_DEPTH = 0.1, 0.25 * MARGIN  # collide.h: narrower than 0.1 x face AND no deeper than margin / 4 -> no contact
+
+
+def sliver_readings(cA, RA, hA, cB, RB, hB, seps, s_star):
+    """Every face axis the kernel may have chosen as reference (within its preference band of the best axis), with the
+    patch numbers of that reading."""
+    d = cB - cA
+    out = []
+    for sv, L, lab, _ in seps:
+        if lab[0] == "E" or sv < s_star - (0.03 + 0.11 * abs(s_star)) - 1e-4:
+            continue
+        if lab[0] == "A":
+            n_ref = L if d @ L >= 0 else -L
+            fp = face_patch(cA, RA, hA, lab[1], n_ref, cB, RB, hB)
+        else:
+            n_ref = -L if d @ L >= 0 else L
+            fp = face_patch(cB, RB, hB, lab[1], n_ref, cA, RA, hA)
+        out.append((lab, fp))
+    return out
+
+
 def pair_base(k, n_pairs, spacing=12.0):
     """Centre of pair k on a compact 3-D lattice around the origin: coordinates stay below ~100, where float32 resolves
     8e-6 (a row of thousands of pairs along x would put the 1e-4 tolerances of this file below float32's resolution)."""
@@ -118,6 +175,15 @@ def _box_pairs(rng, n_pairs):
         reach = he[2 * k] @ np.abs(direction) + he[2 * k + 1] @ np.abs(direction)
         pos[2 * k] = base
         pos[2 * k + 1] = base + direction * reach * rng.uniform(0.55, 1.25)
+        if k % 10 == 9:
+            # diagonal neighbours of a stack: two axis-aligned boxes that (nearly) touch along an edge or at a corner -
+            # the home ground of the sliver rule (patch of no width at depth ~0), scattered +-0.03 around exact touch
+            rot[2 * k] = (0, 0, 0, 1)
+            rot[2 * k + 1] = (0, 0, 0, 1)
+            touch = rng.choice([-1.0, 1.0], size=3) * (he[2 * k] + he[2 * k + 1])
+            if rng.random() < 0.7:
+                touch[rng.integers(3)] *= rng.uniform(0.0, 0.8)  # edge neighbour: real overlap on one axis
+            pos[2 * k + 1] = base + touch + rng.uniform(-0.03, 0.03, size=3)
     shape = np.full(n, physics_amd.SHAPE_BOX, np.uint32)
     return pos.astype(np.float32), rot, shape, he.astype(np.float32)
 
@@ -131,7 +197,7 @@ def test_box_box_manifolds_against_brute_force_sat():
     w.sync()
     man = manifold_dict(w)
     assert all(b == a + 1 and a % 2 == 0 for a, b in man), "a manifold between bodies of different pairs"
-    n_hit = n_miss = n_band = n_edge = 0
+    n_hit = n_miss = n_band = n_edge = n_sliver = 0
     for k in range(n_pairs):
         a, b = 2 * k, 2 * k + 1
         cA, cB = pos[a].astype(np.float64), pos[b].astype(np.float64)
@@ -149,9 +215,19 @@ def test_box_box_manifolds_against_brute_force_sat():
             if got is None:
                 continue
         if got is None:
-            # must-have branch: only when no axis of the FULL set (near-parallel edge pairs included) separates either
+            # must-have branch: only when no axis of the FULL set (near-parallel edge pairs included) separates either -
+            # or under the SLIVER RULE of collide.h: some face reading the kernel may have chosen has a patch narrower
+            # than 0.1 x the smallest half extent of the two faces and no point deeper than a quarter of the margin
+            # (bands of 1e-3 on the width and 1e-4 on the depth)
             s_all, _ = sat_separation(cA, RA, hA, cB, RB, hB, min_cross=1e-6)
-            assert s_all > MARGIN - 1e-3, f"pair {k}: no separating axis (max separation {s_all:.5f}), yet no manifold"
+            if s_all > MARGIN - 1e-3:
+                continue
+            # (a reading whose patch is EMPTY - nothing of the incident face lies over the reference face: boxes that
+            # face each other across a gap on two axes at once - has no points to report either)
+            slivers = [lab for lab, fp in sliver_readings(cA, RA, hA, cB, RB, hB, seps, s_star)
+                       if fp is None or (fp[0] < SLIVER_REL * fp[1] + 1e-3 and fp[2] <= SLIVER_DEPTH + 1e-4)]
+            assert slivers, f"pair {k}: no separating axis (max separation {s_all:.5f}), no sliver reading, yet no manifold"
+            n_sliver += 1
             continue
         n_hit += 1
         count, normal, pts = got
@@ -214,11 +290,16 @@ def test_box_box_manifolds_against_brute_force_sat():
             if bad is None and count >= 2 and len({tuple(np.round(p, 4)) for p in pts[:, :3]}) != count:
                 bad = "duplicate contact points"
             if bad is None:
+                # ... and it is not what the sliver rule says is no contact (same bands, from the other side)
+                fp = face_patch(cR, RR, hR, axis, n_ref, cI, RI, hI)
+                if fp is not None and fp[0] < SLIVER_REL * fp[1] - 1e-3 and fp[2] <= SLIVER_DEPTH - 1e-4:
+                    bad = f"a sliver (patch width {fp[0]:.5f} of face {fp[1]:.3f}, deepest {fp[2]:.5f}) came back as a contact"
+            if bad is None:
                 problems = None
                 break
             problems.append((lab, bad))
         assert problems is None, f"pair {k}: manifold fits no reading of its normal: {problems}\n{pts}"
-    assert n_hit > 800 and n_miss > 300 and n_edge > 20, (n_hit, n_miss, n_band, n_edge)  # the sample covers all regimes
+    assert n_hit > 800 and n_miss > 300 and n_edge > 20 and n_sliver > 30, (n_hit, n_miss, n_band, n_edge, n_sliver)  # the sample covers all regimes
 
 
 # ---------------------------------------------------------------- narrow phase: spheres

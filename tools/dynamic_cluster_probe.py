@@ -17,7 +17,7 @@ DT = 16_666_667
 sc = scenes.c5(16, 130, 16)
 states, ran, active = [], [], 0
 for extra in (0, physics_amd.FLAG_SOLVER_PER_COLOR):
-    w = physics_amd.World(sc.config(flags=sc.flags | extra))
+    w = physics_amd.World(sc.config(flags=sc.flags | (extra or physics_amd.FLAG_SOLVER_CLUSTER)))
     sc.populate(w)
     w.update_n(DT, 8)
     w.profile_enable(True)
