@@ -38,7 +38,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s achievable
-PROFILE_ROUND = "r2"
+PROFILE_ROUND = "r3"
 
 KERNEL_OF_STAGE = {
     "step_full": "k_step_full", "velocity_aabb": "k_step_velocity_aabb",
@@ -48,9 +48,16 @@ KERNEL_OF_STAGE = {
     "rows": "k_rows_build",    # + k_color_hist / k_color_offsets / k_color_place beyond 40k manifolds
     "solve": "k_solve_color",  # k_solve_color_quad (four lanes per manifold) unless PHYS_DEBUG_COLOR_KERNEL=lane
     "solve_tail": "k_solve_tail", "solve_flow": "k_solve_flow", "solve_cluster": "k_solve_cluster", "position": "k_step_position",
+    "constraints": "k_constraint_solve",
 }
 
-DEFAULT_PREROLL = {"c1": 100, "c2": 150, "c3": 150, "c5": 30, "t1m": 100, "c4": 0}
+# t1m_settled: the 1M cubes after every column has come to rest (the top cube falls 50 units: 192 updates, then the pile
+# settles) - the heaviest state of the north_star scene
+DEFAULT_PREROLL = {"c1": 100, "c2": 150, "c3": 150, "c5": 30, "t1m": 100, "c4": 0, "t1m_settled": 600, "ref_1m": 10, "ref_cg": 10}
+WORKLOAD_NAMES = {"t1m_settled": "T_1M_cubes_settled"}
+# the kernel a sub-record is ABOUT, where that is not simply the longest stage of the step (the kernels that
+# restate the reference's own functions, and the pair search of the broad-phase-only configuration)
+ROOFLINE_STAGE = {"ref_1m": "step_full", "ref_cg": "constraints", "c4": "pairs"}
 
 
 def stage_bytes(stage, st, iters, cluster=False):
@@ -60,6 +67,9 @@ def stage_bytes(stage, st, iters, cluster=False):
     mb = m - st["n_ground_manifolds"]
     if stage == "step_full":
         return 120 * n
+    if stage == "constraints":
+        # per CG iteration and row: p, Ap, r, x read, x, r, p, Ap written, the column table (60 B)
+        return 60 * st.get("cg_rows", 0) * st.get("cg_iterations_per_update", 0.0)
     if stage == "velocity_aabb":
         return 132 * n
     if stage == "position":
@@ -116,7 +126,7 @@ def committed_profile_fields(workload_key, kernel, window, st):
         return None, None, None, f"no committed profile for this workload (profiles/{PROFILE_ROUND}_{workload_key}_window.json)"
     cw, cs = c.get("window", {}), c.get("scene_stats", {})
     same_window = all(cw.get(k) == window[k] for k in ("preroll", "warmup", "steps"))
-    same_state = all(cs.get(k) == st[k] for k in ("n_bodies", "n_manifolds", "n_colors"))
+    same_state = all(cs.get(k) == st[k] for k in ("n_bodies", "n_pairs", "n_manifolds", "n_colors"))
     if not (same_window and same_state):
         return None, None, None, (f"committed profile covers window {cw} at {cs.get('n_manifolds')} manifolds / "
                                   f"{cs.get('n_colors')} colours; this run: {window} at {st['n_manifolds']} / {st['n_colors']}: "
@@ -131,7 +141,7 @@ def committed_profile_fields(workload_key, kernel, window, st):
 
 def stats_dict(s):
     return {f: int(getattr(s, f)) for f in ("n_bodies", "n_pairs", "n_manifolds", "n_contacts", "n_colors",
-                                            "color_rounds", "n_ground_manifolds")}
+                                            "color_rounds", "n_ground_manifolds", "cg_iterations")}
 
 
 class Rig:
@@ -255,11 +265,21 @@ def profile_window(rig, preroll, warmup, steps, workload_key):
     rig.advance(w, warmup)
     w.sync()
     w.profile_enable(True)
-    rig.advance(w, steps)
+    cg_total = 0
+    if rig.scene.constraints:
+        for _ in range(steps):  # the CG iteration count is a per-update figure: read it after every update
+            rig.advance(w, 1)
+            w.sync()
+            cg_total += int(w.get_stats().cg_iterations)
+    else:
+        rig.advance(w, steps)
     w.sync()
     prof, psteps = w.profile_get()
     w.profile_enable(False)
     st = stats_dict(w.get_stats())
+    if rig.scene.constraints:
+        st["cg_rows"] = 3 * len(rig.scene.constraints)
+        st["cg_iterations_per_update"] = cg_total / max(steps, 1)
     counts = [int(c) for c in w.get_color_counts()[:st["n_colors"]]]
     w.close()
     iters = rig.iters
@@ -271,6 +291,8 @@ def profile_window(rig, preroll, warmup, steps, workload_key):
     if not kernel_stages:
         return None, table, st
     dom = max(kernel_stages, key=lambda s: table[s]["ms_per_step"])
+    if ROOFLINE_STAGE.get(workload_key) in table:
+        dom = ROOFLINE_STAGE[workload_key]
     cluster = "solve_cluster" in table
     b_step = stage_bytes(dom, st, iters, cluster)
     if dom == "solve" and "solve_tail" in table:
@@ -332,15 +354,21 @@ def cpu_baseline(scene, state, window_start, sample_steps, budget_s=14.0):
     from physics_amd.scenes import DT_NANOS
     pos, rot, lin, ang = state
 
+    cg_iters = [0]
+
     def timed(threads):
         o = ob.OracleWorld(scene.config(), trig=ob.TRIG_DET)
-        o.set_bodies(pos, rot=rot, lin_vel=lin, ang_vel=ang, shape_type=scene.shape_type, half_extent=scene.half_extent)
+        scene.populate(o, (pos, rot, lin, ang))
         o.set_threads(threads)
         o.update(DT_NANOS)
         done, t0 = 0, time.perf_counter()
-        while done < sample_steps:
+        # at least `sample_steps` steps, and at least a second of them where a step is cheap (at most 400); never
+        # beyond the budget
+        while done < sample_steps or (time.perf_counter() - t0 < 1.0 and done < 400):
             o.update(DT_NANOS)
             done += 1
+            if scene.constraints and threads == 1:
+                cg_iters[0] += int(o.get_stats().cg_iterations)
             if time.perf_counter() - t0 > budget_s:
                 break
         dt = time.perf_counter() - t0
@@ -351,8 +379,14 @@ def cpu_baseline(scene, state, window_start, sample_steps, budget_s=14.0):
     # additionally the OpenMP variant of the same oracle (same bits for any thread count) on the host
     # cores this process may use, at most 16 (the CPU share of one GPU on the bench boxes)
     cores = min(len(os.sched_getaffinity(0)), 16)
-    km, dt_mt = timed(cores) if cores > 1 else (k1, dt)
-    return {"value": round(scene.n * k1 / dt, 1), "unit": "body-steps/s", "cores": 1, "kind": "port",
+    km, dt_mt = timed(cores) if cores > 1 and not scene.constraints else (k1, dt)  # (the constraint path has no OpenMP loops)
+    extra = {}
+    if scene.constraints and cg_iters[0]:
+        extra = {"cg_iterations_per_update": round(cg_iters[0] / k1, 2),
+                 "us_per_update": round(1e6 * dt / k1, 1),
+                 "note_cg": "whole PhysicsState::update of the oracle (gathers of 6N vectors, assembly, CG, integrate) per update; "
+                            "the restatement keeps the reference's per-row heap vectors (sparse_matrix.rs:30,44)"}
+    return {**extra, "value": round(scene.n * k1 / dt, 1), "unit": "body-steps/s", "cores": 1, "kind": "port",
             "steps_per_sec": round(k1 / dt, 4),
             "sample": f"oracle (scalar C++ restatement of the reference step + CPU collision stages, 1 thread; the Rust "
                       f"reference is not buildable here: no cargo/rustc), workload {scene.name}, seeded with the GPU world's "
@@ -376,6 +410,8 @@ def measure_workload(rig, args, preroll, reps, with_cpu):
     med = statistics.median(times)
     n_total = rig.scene.n * rig.world_size
     pairs_total = rig.sum_over_ranks(float(st["n_pairs"] + cross))
+    if rig.scene.constraints:
+        st["cg_rows"] = 3 * len(rig.scene.constraints)
     rec = {
         "value": round(n_total * args.steps / med, 1), "steps_per_sec": round(args.steps / med, 2),
         "ms_per_step": round(1e3 * med / args.steps, 4),
@@ -391,8 +427,9 @@ def measure_workload(rig, args, preroll, reps, with_cpu):
         sps, slowest = timed_period(rig, preroll, args.warmup)
         rec["full_period"] = {"steps": 64, "steps_per_sec": round(sps, 2), "slowest_step_ms": round(slowest, 3),
                               "note": "64 consecutive steps from the start of the timed window, synchronised after every step: "
-                                      "contains exactly one full re-colouring update (every 64th update, contact_solve.h), which the "
-                                      "timed window may not; the scene keeps evolving over the period (a growing pile gets slower)"}
+                                      "contains exactly one rebuild of the persistent colour table (every 64th update; colours are "
+                                      "never re-made: contact_solve.h) and, with dynamic clusters, eight deals of the homes; the scene "
+                                      "keeps evolving over the period (a growing pile gets slower)"}
     # sharded: every rank steps through the profile window (the exchange is a collective); rank 0 reports its slab
     roof, table = None, {}
     if rig.rank == 0 or rig.sharded:
@@ -421,7 +458,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20, help="timed steps K per repetition")
     ap.add_argument("--warmup", type=int, default=5, help="untimed warm-up steps W in front of the K timed ones")
     ap.add_argument("--reps", type=int, default=5, help="repetitions of the timed window (median reported)")
-    ap.add_argument("--workload", default="c5", choices=["c1", "c2", "c3", "c5", "t1m", "c4"])
+    ap.add_argument("--workload", default="c5", choices=["c1", "c2", "c3", "c5", "t1m", "c4", "t1m_settled", "ref_1m", "ref_cg"])
     ap.add_argument("--preroll", type=int, default=-1, help="untimed set-up steps in front of the warm-up (default per workload)")
     ap.add_argument("--cpu-steps", type=int, default=4, help="timed oracle steps of the CPU sample (bounded by 14 s per variant)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -535,12 +572,26 @@ def main():
     if rank == 0 and not sharded and not args.no_extra and args.workload == "c5":
         # the other single-GPU configurations, measured the same way (fewer repetitions: they are sub-records)
         others = {}
-        for wl in ("t1m", "c3", "c2"):
+        for wl in ("t1m", "c3", "c2", "c4", "t1m_settled", "ref_1m", "ref_cg"):
             r2 = Rig(wl, 0, 1, local_rank, None, False, False)
             rr = measure_workload(r2, args, DEFAULT_PREROLL[wl], 3, not args.no_cpu_baseline)
-            rr["workload"] = r2.scene.name
-            if wl == "t1m":
+            rr["workload"] = WORKLOAD_NAMES.get(wl, r2.scene.name)
+            if wl in ("t1m", "t1m_settled"):
                 rr["north_star_target_steps_per_sec"] = 60.0
+            if wl == "ref_cg" and "roofline" in rr and "cpu_baseline" in rr:
+                # k_constraint_solve beside the one-thread oracle, per CG iteration - said plainly
+                it_gpu = rr["roofline"]["scene_stats_after_window"].get("cg_iterations_per_update", 0.0)
+                us_gpu = rr["stages"]["constraints"]["avg_launch_us"] / max(it_gpu, 1e-9)
+                cb = rr["cpu_baseline"]
+                us_cpu = cb.get("us_per_update", 0.0) / max(cb.get("cg_iterations_per_update", 1e-9), 1e-9)
+                rr["cg"] = {"rows": rr["scene_stats"].get("cg_rows"), "iterations_per_update_gpu_window": round(it_gpu, 2),
+                            "gpu_us_per_cg_iteration": round(us_gpu, 2),
+                            "cpu_oracle_us_per_cg_iteration": round(us_cpu, 2),
+                            "gpu_kernel_slower_than_one_cpu_thread": bool(us_gpu > us_cpu),
+                            "note": "k_constraint_solve is ONE workgroup that keeps nalgebra's summation order (8 strided "
+                                    "accumulator chains per dot, three dots per iteration) so that lambda and the iteration "
+                                    "count equal the reference's bit for bit; gpu figure = kernel time (set-up included) / "
+                                    "iterations, cpu figure = whole oracle update / iterations"}
             others[wl] = rr
         out["other_workloads"] = others
     if dist is not None:

@@ -170,6 +170,21 @@ int32_t phys_get_instance_matrices(phys_world* w, float* out /*16n*/);
 /* previous_solution (physics.rs:30): warm-start lambda; *n_rows = 0 when None */
 int32_t phys_get_lambda(phys_world* w, float* lambda_out, uint64_t cap, uint64_t* n_rows);
 
+/* SparseMatrix { add_block, multiply_vector, tr_multiply_vector } (sparse_matrix.rs:16-50) in its GENERAL form, on the
+ * device: a block-sparse nrows x ncols matrix given as a list of dense blocks - block b covers rows [i, i + i_length) and
+ * columns [j, j + j_length), block_desc = {i, j, i_length, j_length} per block, data = the blocks one after the other,
+ * each ROW-major (the reference's from_vec is column-major: the caller transposes) - times a vector: out = M v
+ * (transpose == 0: v has ncols entries, out nrows; sparse_matrix.rs:25-37) or out = M^T v (transpose != 0: v has nrows,
+ * out ncols; :39-50). Overlapping blocks accumulate IN LIST ORDER and the inner sum of a block row runs left to right, as
+ * the reference's loops do, so the result equals the reference's bit for bit (one lane per output entry walks the blocks
+ * that touch it, in list order). All pointers are HOST memory; the call uploads, runs the kernel on `device` and
+ * downloads. The constraint solve inside phys_update uses the specialised identity-selector form of the same product
+ * (the reference's two constraint kinds have nothing else); this entry point is the general one, held to the
+ * reference's own unit tests (sparse_matrix.rs:65-119). A block reaching outside the matrix, or a vector of the wrong
+ * length (the reference: assert_eq panic, sparse_matrix.rs:26,40) is PHYS_ERR_INVALID_ARG. */
+int32_t phys_block_spmv(int32_t device, uint64_t nrows, uint64_t ncols, uint64_t nblocks, const uint64_t* block_desc /*4 per block*/,
+                        const float* data, const float* vec, uint64_t vec_len, int32_t transpose, float* out);
+
 /* broad-phase of the current poses: candidate pairs (i < j) with overlapping fattened AABBs,
  * sorted by (i, j). pairs_out may be NULL to query the count. (new: SURVEY §8 A10) */
 int32_t phys_broadphase(phys_world* w, uint32_t* pairs_out /*2*cap*/, uint64_t cap, uint64_t* n_pairs);

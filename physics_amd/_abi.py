@@ -149,6 +149,7 @@ PROTOTYPES = {
     "phys_get_forces": (C.c_int32, [C.c_void_p, f32p, f32p]),
     "phys_get_instance_matrices": (C.c_int32, [C.c_void_p, f32p]),
     "phys_get_lambda": (C.c_int32, [C.c_void_p, f32p, C.c_uint64, u64p]),
+    "phys_block_spmv": (C.c_int32, [C.c_int32, C.c_uint64, C.c_uint64, C.c_uint64, u64p, f32p, f32p, C.c_uint64, C.c_int32, f32p]),
     "phys_broadphase": (C.c_int32, [C.c_void_p, u32p, C.c_uint64, u64p]),
     "phys_get_aabbs": (C.c_int32, [C.c_void_p, f32p]),
     "phys_get_manifolds": (C.c_int32, [C.c_void_p, u32p, u32p, f32p, f32p, C.c_uint64, u64p]),

@@ -168,7 +168,7 @@ int32_t phys_destroy(phys_world* w) {
     if (w->stream) (void)hipStreamSynchronize(w->stream);
     DevBuf<float>* fb[] = {&w->pos, &w->rot, &w->vel, &w->force, &w->torque, &w->inv_inertia_diag,
                            &w->inv_inertia, &w->half_extent, &w->aabb, &w->cg_x, &w->cg_r, &w->cg_p, &w->cg_ap,
-                           &w->cg_rhs, &w->cg_c, &w->cg_scratch, &w->man_geo, &w->row_n,
+                           &w->cg_rhs, &w->cg_c, &w->cg_scratch, &w->cg_jl, &w->man_geo, &w->row_n,
                            &w->row_pt, &w->row_tb, &w->row_acc, &w->row_all, &w->flow_vel, &w->sorted_box, &w->slot_box};
     for (auto* b : fb) b->free();
     DevBuf<uint32_t>* ub[] = {&w->shape, &w->global_id, &w->cg_status, &w->bucket_of, &w->bucket_count,
@@ -356,22 +356,21 @@ static int32_t enqueue_update(phys_world* w, float dt) {
     const bool have_constraints = !w->constraints.empty();
     bool gravity_pending = true;
     if (have_constraints) {
-        // the constraint right-hand side reads Q = force/torque accumulators including gravity
-        // (constraints.rs:92-104), so gravity is materialised first, then lambda, then the scatter
-        launch_apply_gravity(w);
-        gravity_pending = false;
+        // the constraint right-hand side reads Q = force/torque accumulators including gravity (constraints.rs:92-104):
+        // the constraint kernel adds gravity to the accumulators of the bodies it reads, and the step kernel adds
+        // J^T lambda to entity 0 behind its own gravity addition - the reference's order, without a pass over all bodies
         const int32_t rc = constraints_alloc(w);
         if (rc != PHYS_OK) return rc;
-        launch_constraint_phase(w);
+        launch_constraint_phase(w, gravity_pending);
     }
     if (!collisions) {
-        launch_step_full(w, dt, gravity_pending);
+        launch_step_full(w, dt, gravity_pending, have_constraints);
     } else {
         // per-step state: zeroed by the first kernel of the step itself; every 32nd step a memset in front of it
         // also restarts the running extent bound (which that kernel raises, so it cannot zero it)
         const bool restart_extent = w->steps % 32 == 0 || w->step_zero_reset_bytes % 16 != 0 || (w->step_zero_reset_bytes >> 36) != 0;
         if (restart_extent) zero_step_state(w, /*including_extent=*/true);
-        launch_step_velocity_aabb(w, dt, gravity_pending, /*zero_step=*/!restart_extent);
+        launch_step_velocity_aabb(w, dt, gravity_pending, /*zero_step=*/!restart_extent, have_constraints);
         launch_broadphase(w);
         if (!(w->cfg.flags & PHYS_FLAG_BROADPHASE_ONLY)) {
             launch_narrowphase(w);

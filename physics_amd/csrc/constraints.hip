@@ -27,21 +27,43 @@ struct CgParams {
     uint32_t n_cols;  // distinct selected columns
     uint32_t max_iterations;
     float max_error, min_error;
+    // apply_gravity (physics.rs:87-94) still pending for this update: Q = accumulator + gravity is formed here for the
+    // constrained bodies (the same addition apply_gravity makes), instead of a pass over all N bodies that materialises
+    // gravity in the accumulators only for this kernel to read a handful of them back
+    uint32_t gravity_pending;
+    float g_force[3], g_torque[3];
 };
 
 constexpr int kCgThreads = 1024;
 
 // nalgebra dotc on Dyn vectors: 8 strided accumulators, then (acc0+acc4) + (acc1+acc5) + ..., then the tail.
 // Lanes 0..7 of the calling wave each run one accumulator chain; the result is returned to every lane.
+// The chains are n/8 DEPENDENT additions each and cannot be shortened without changing the sum (and with it the iteration
+// at which CG stops); what can be taken out of them is everything else: the products are made by the whole workgroup,
+// kDotChunk at a time, into LDS (rounded once, as `acc += a * b` rounds them without contraction), and a chain then reads
+// eight of them per trip from LDS instead of waiting for two global loads per addition (24k rows: 3072 links per chain).
+constexpr uint32_t kDotChunk = 8192;  // products staged per trip (32 KiB of LDS)
 __device__ __forceinline__ float dyn_dot8(const float* __restrict__ a, const float* __restrict__ b, uint32_t n,
-                                          float* __restrict__ lds8) {
+                                          float* __restrict__ lds8, float* __restrict__ prod) {
     const uint32_t lane = threadIdx.x;
-    if (lane < 8) {
-        float acc = 0.0f;
-        const uint32_t full = n & ~7u;
-        for (uint32_t i = lane; i < full; i += 8) acc += a[i] * b[i];
-        lds8[lane] = acc;
+    const uint32_t full = n & ~7u;
+    float acc = 0.0f;
+    for (uint32_t base = 0; base < full; base += kDotChunk) {
+        const uint32_t m = full - base < kDotChunk ? full - base : kDotChunk;  // a multiple of 8
+        for (uint32_t i = threadIdx.x; i < m; i += kCgThreads) prod[i] = a[base + i] * b[base + i];
+        __syncthreads();
+        if (lane < 8) {
+            uint32_t i = lane;
+            for (; i + 56 < m; i += 64) {  // eight links per trip: the LDS reads of a trip are independent of its additions
+                const float p0 = prod[i], p1 = prod[i + 8], p2 = prod[i + 16], p3 = prod[i + 24], p4 = prod[i + 32],
+                            p5 = prod[i + 40], p6 = prod[i + 48], p7 = prod[i + 56];
+                acc += p0; acc += p1; acc += p2; acc += p3; acc += p4; acc += p5; acc += p6; acc += p7;
+            }
+            for (; i < m; i += 8) acc += prod[i];
+        }
+        __syncthreads();
     }
+    if (lane < 8) lds8[lane] = acc;
     __syncthreads();
     float res = 0.0f;
     res += lds8[0] + lds8[4];
@@ -108,10 +130,12 @@ __global__ __launch_bounds__(kCgThreads) void k_constraint_solve(
     CgParams cp, const Constraint* __restrict__ cons, const uint32_t* __restrict__ col_ptr,
     const uint32_t* __restrict__ col_rows, const uint32_t* __restrict__ col_id, const uint32_t* __restrict__ row_cidx,
     float* __restrict__ col_w, const float* __restrict__ pos, const float* __restrict__ rot,
-    const float* __restrict__ vel, float* __restrict__ force, float* __restrict__ torque, float* __restrict__ x_prev, float* __restrict__ x, float* __restrict__ r,
+    const float* __restrict__ vel, const float* __restrict__ force, const float* __restrict__ torque, float* __restrict__ x_prev, float* __restrict__ x, float* __restrict__ r,
     float* __restrict__ p, float* __restrict__ ap, float* __restrict__ rhs, float* __restrict__ tcol,
-    uint32_t* __restrict__ status /* [0] converged, [1] iterations, [2] previous_solution.is_some() */) {
+    uint32_t* __restrict__ status /* [0] converged, [1] iterations, [2] previous_solution.is_some() */,
+    float* __restrict__ jl /* 6: J^T lambda of entity 0, added to its accumulators by the step kernel when status[0] */) {
     __shared__ float lds8[8];
+    __shared__ float prod[kDotChunk];
     __shared__ float lds16[kCgThreads / 64];
     __shared__ int s_done;
     const uint32_t n = 3 * cp.n_constraints;
@@ -126,7 +150,9 @@ __global__ __launch_bounds__(kCgThreads) void k_constraint_solve(
         if (con.kind == 0u) {
             const v3 x0 = ld3(pos, b);
             cv[0] = x0.x - con.target[0]; cv[1] = x0.y - con.target[1]; cv[2] = x0.z - con.target[2];
-            const v3 v = ld_vel(vel, b).v, F = ld3(force, b);
+            const v3 v = ld_vel(vel, b).v;
+            v3 F = ld3(force, b);
+            if (cp.gravity_pending) F = v3_add(F, v3_make(cp.g_force[0], cp.g_force[1], cp.g_force[2]));  // apply_force_at_offset: force += F
             qd[0] = v.x; qd[1] = v.y; qd[2] = v.z;
             Q[0] = F.x; Q[1] = F.y; Q[2] = F.z;
         } else {
@@ -135,7 +161,9 @@ __global__ __launch_bounds__(kCgThreads) void k_constraint_solve(
             float rpy[3];
             quat_euler_angles(q, rpy);
             cv[0] = rpy[0] - con.target[0]; cv[1] = rpy[1] - con.target[1]; cv[2] = rpy[2] - con.target[2];
-            const v3 wv = ld_vel(vel, b).w, T = ld3(torque, b);
+            const v3 wv = ld_vel(vel, b).w;
+            v3 T = ld3(torque, b);
+            if (cp.gravity_pending) T = v3_add(T, v3_make(cp.g_torque[0], cp.g_torque[1], cp.g_torque[2]));  // torque += offset x F
             qd[0] = wv.x; qd[1] = wv.y; qd[2] = wv.z;
             Q[0] = T.x; Q[1] = T.y; Q[2] = T.z;
         }
@@ -162,8 +190,8 @@ __global__ __launch_bounds__(kCgThreads) void k_constraint_solve(
     bool converged = false;
     for (; it < cp.max_iterations; ++it) {
         apply_A(p, ap, tcol, cp, col_ptr, col_rows, col_w, row_cidx);  // :32
-        const float rk = dyn_dot8(r, r, n, lds8);                     // :33
-        const float alpha = rk / dyn_dot8(p, ap, n, lds8);            // :34
+        const float rk = dyn_dot8(r, r, n, lds8, prod);                     // :33
+        const float alpha = rk / dyn_dot8(p, ap, n, lds8, prod);            // :34
         for (uint32_t i = threadIdx.x; i < n; i += kCgThreads) {
             x[i] = x[i] + alpha * p[i];   // :35
             r[i] = r[i] - alpha * ap[i];  // :37
@@ -173,21 +201,21 @@ __global__ __launch_bounds__(kCgThreads) void k_constraint_solve(
         if (threadIdx.x == 0) s_done = ramax < bound ? 1 : 0;  // :38
         __syncthreads();
         if (s_done) { converged = true; ++it; break; }
-        const float beta = dyn_dot8(r, r, n, lds8) / rk;  // :42
+        const float beta = dyn_dot8(r, r, n, lds8, prod) / rk;  // :42
         for (uint32_t i = threadIdx.x; i < n; i += kCgThreads) p[i] = r[i] + beta * p[i];  // :43
         __syncthreads();
     }
     if (converged) {
         // previous_solution = Some(solution) (physics.rs:46)
         for (uint32_t i = threadIdx.x; i < n; i += kCgThreads) x_prev[i] = x[i];
-        // J^T lambda restricted to body 0, then the quirk-Q3 scatter: entities[0] only (physics.rs:47-50)
+        // J^T lambda restricted to body 0 for the quirk-Q3 scatter: entities[0] only (physics.rs:47-50). The addition
+        // itself is made by the step kernel, behind gravity as in the reference (force = (force + gravity) + J^T lambda)
         if (threadIdx.x < 6) {
             float s = 0.0f;
             for (uint32_t u = 0; u < cp.n_cols; ++u)
                 if (col_id[u] == threadIdx.x)
                     for (uint32_t k = col_ptr[u]; k < col_ptr[u + 1]; ++k) s += x[col_rows[k]];
-            if (threadIdx.x < 3) force[threadIdx.x] = force[threadIdx.x] + s;
-            else torque[threadIdx.x - 3] = torque[threadIdx.x - 3] + s;
+            jl[threadIdx.x] = s;
         }
     }
     if (threadIdx.x == 0) {
@@ -223,6 +251,7 @@ int32_t constraints_alloc(phys_world* w) {
     PHYS_HIP_TRY(w->cg_r.resize(n)); PHYS_HIP_TRY(w->cg_p.resize(n)); PHYS_HIP_TRY(w->cg_ap.resize(n));
     PHYS_HIP_TRY(w->cg_rhs.resize(n)); PHYS_HIP_TRY(w->cg_scratch.resize(2 * U + 1));  // tcol | col_w
     PHYS_HIP_TRY(w->cg_status.resize(4));
+    PHYS_HIP_TRY(w->cg_jl.resize(8));
     uint32_t* base = w->cg_cols.p;
     PHYS_HIP_TRY(hipMemcpy(w->d_constraints.p, w->constraints.data(), C * sizeof(Constraint), hipMemcpyHostToDevice));
     PHYS_HIP_TRY(hipMemcpy(base, col_id.data(), U * 4, hipMemcpyHostToDevice));
@@ -236,10 +265,19 @@ int32_t constraints_alloc(phys_world* w) {
     return PHYS_OK;
 }
 
-void launch_constraint_phase(phys_world* w) {
+void launch_constraint_phase(phys_world* w, bool gravity_pending) {
     const uint32_t C = (uint32_t)w->constraints.size();
     if (C == 0) return;
     CgParams cp;
+    cp.gravity_pending = gravity_pending ? 1u : 0u;
+    {
+        const float* F = w->cfg.gravity_force;
+        const float* o = w->cfg.gravity_offset;
+        for (int k = 0; k < 3; ++k) cp.g_force[k] = F[k];
+        cp.g_torque[0] = o[1] * F[2] - o[2] * F[1];  // offset.cross(&force), rigid_body.rs:60 (as integrate.hip make_params)
+        cp.g_torque[1] = o[2] * F[0] - o[0] * F[2];
+        cp.g_torque[2] = o[0] * F[1] - o[1] * F[0];
+    }
     cp.n_constraints = C;
     cp.n_cols = w->cg_n_cols;
     cp.max_iterations = w->cfg.cg_max_iterations;
@@ -251,7 +289,99 @@ void launch_constraint_phase(phys_world* w) {
     hipLaunchKernelGGL(k_constraint_solve, dim3(1), dim3(kCgThreads), 0, w->stream, cp, w->d_constraints.p, base + U,
                        base + 2 * U + 1, base, base + 2 * U + 1 + n, w->cg_scratch.p + U, w->pos.p, w->rot.p, w->vel.p,
                        w->force.p, w->torque.p, w->cg_x.p, w->cg_x.p + n, w->cg_r.p, w->cg_p.p,
-                       w->cg_ap.p, w->cg_rhs.p, w->cg_scratch.p, w->cg_status.p);
+                       w->cg_ap.p, w->cg_rhs.p, w->cg_scratch.p, w->cg_status.p, w->cg_jl.p);
+}
+
+// ---- the general block-sparse product (sparse_matrix.rs:16-50) -----------------------------------------------------
+// One lane per OUTPUT entry. entry_ptr / entry_blk / entry_loc list, for every output entry, the (block, local row or
+// column) pairs that add to it, in add_block order - so overlapping blocks accumulate in the reference's order - and the
+// inner product of a block row (or column) runs left to right: `result = t` for the first term, `t + result` after
+// (nalgebra's gemv is an axpy per column, the way the oracle restates it).
+struct BlockDesc { uint32_t i, j, il, jl, off; };
+__global__ __launch_bounds__(256) void k_block_spmv(uint32_t n_out, int transpose, const BlockDesc* __restrict__ blk,
+                                                    const uint32_t* __restrict__ entry_ptr, const uint32_t* __restrict__ entry_blk,
+                                                    const uint32_t* __restrict__ entry_loc, const float* __restrict__ data,
+                                                    const float* __restrict__ vec, float* __restrict__ out) {
+    const uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= n_out) return;
+    float res = 0.0f;  // OVector::repeat(n, 0.0)
+    for (uint32_t e = entry_ptr[o]; e < entry_ptr[o + 1]; ++e) {
+        const BlockDesc b = blk[entry_blk[e]];
+        const uint32_t l = entry_loc[e];
+        float result = 0.0f;  // OVector::zeros(1)
+        if (!transpose) {
+            for (uint32_t c = 0; c < b.jl; ++c) {  // row(l) . vector.rows(j, j_length)
+                const float t = data[b.off + l * b.jl + c] * vec[b.j + c];
+                result = c == 0 ? t : t + result;
+            }
+        } else {
+            for (uint32_t r = 0; r < b.il; ++r) {  // column(l)^T . vector.rows(i, i_length)
+                const float t = data[b.off + r * b.jl + l] * vec[b.i + r];
+                result = r == 0 ? t : t + result;
+            }
+        }
+        res += result;  // res[(block.i + row, 0)] += result[(0, 0)]
+    }
+    out[o] = res;
 }
 
 }  // namespace phys
+
+extern "C" int32_t phys_block_spmv(int32_t device, uint64_t nrows, uint64_t ncols, uint64_t nblocks, const uint64_t* block_desc,
+                                   const float* data, const float* vec, uint64_t vec_len, int32_t transpose, float* out) {
+    using namespace phys;
+    auto bad = [](const char* msg) { set_error(msg); return (int32_t)PHYS_ERR_INVALID_ARG; };
+    if ((nblocks && (!block_desc || !data)) || !vec || !out) return bad("null argument");
+    if (nrows >= 0x7FFFFFFFull || ncols >= 0x7FFFFFFFull || nblocks >= 0x7FFFFFFFull) return bad("matrix too large (u32 indices)");
+    if (vec_len != (transpose ? nrows : ncols)) return bad("vector length does not match the matrix (reference: assert_eq, sparse_matrix.rs:26,40)");
+    const uint64_t n_out = transpose ? ncols : nrows;
+    std::vector<BlockDesc> blk(nblocks);
+    std::vector<uint32_t> entry_ptr(n_out + 1, 0u);
+    uint64_t off = 0;
+    for (uint64_t b = 0; b < nblocks; ++b) {
+        const uint64_t i = block_desc[4 * b], j = block_desc[4 * b + 1], il = block_desc[4 * b + 2], jl = block_desc[4 * b + 3];
+        if (i + il > nrows || j + jl > ncols) return bad("a block reaches outside the matrix (reference: index panic)");
+        if (off + il * jl >= 0xFFFFFFFFull) return bad("block data too large (u32 offsets)");
+        blk[b] = BlockDesc{(uint32_t)i, (uint32_t)j, (uint32_t)il, (uint32_t)jl, (uint32_t)off};
+        off += il * jl;
+        const uint64_t first = transpose ? j : i, count = transpose ? jl : il;
+        for (uint64_t k = 0; k < count; ++k) entry_ptr[first + k + 1] += 1u;
+    }
+    for (uint64_t o = 0; o < n_out; ++o) entry_ptr[o + 1] += entry_ptr[o];
+    const uint32_t n_entries = entry_ptr[n_out];
+    std::vector<uint32_t> entry_blk(n_entries ? n_entries : 1), entry_loc(n_entries ? n_entries : 1), cursor(entry_ptr.begin(), entry_ptr.end() - 1);
+    for (uint64_t b = 0; b < nblocks; ++b) {  // blocks in list order: every entry's list comes out in that order
+        const uint32_t first = transpose ? blk[b].j : blk[b].i, count = transpose ? blk[b].jl : blk[b].il;
+        for (uint32_t k = 0; k < count; ++k) {
+            const uint32_t at = cursor[first + k]++;
+            entry_blk[at] = (uint32_t)b;
+            entry_loc[at] = k;
+        }
+    }
+    if (n_out == 0) return PHYS_OK;
+    int count_dev = 0;
+    if (hipGetDeviceCount(&count_dev) != hipSuccess || device < 0 || device >= count_dev) {
+        set_error("no HIP device visible: libphysics_hip has no CPU fallback");
+        return PHYS_ERR_NO_DEVICE;
+    }
+    PHYS_HIP_TRY(hipSetDevice(device));
+    DevBuf<uint8_t> d_blk, d_data, d_vec, d_out;
+    DevBuf<uint32_t> d_ptr, d_eb, d_el;
+    struct Free { DevBuf<uint8_t>*a, *b, *c, *d; DevBuf<uint32_t>*e, *f, *g; ~Free() { a->free(); b->free(); c->free(); d->free(); e->free(); f->free(); g->free(); } }
+        cleanup{&d_blk, &d_data, &d_vec, &d_out, &d_ptr, &d_eb, &d_el};
+    PHYS_HIP_TRY(d_blk.resize(std::max<size_t>(blk.size(), 1) * sizeof(BlockDesc)));
+    PHYS_HIP_TRY(d_data.resize(std::max<size_t>(off, 1) * 4)); PHYS_HIP_TRY(d_vec.resize(std::max<size_t>(vec_len, 1) * 4)); PHYS_HIP_TRY(d_out.resize(n_out * 4));
+    PHYS_HIP_TRY(d_ptr.resize(n_out + 1)); PHYS_HIP_TRY(d_eb.resize(entry_blk.size())); PHYS_HIP_TRY(d_el.resize(entry_loc.size()));
+    if (!blk.empty()) PHYS_HIP_TRY(hipMemcpy(d_blk.p, blk.data(), blk.size() * sizeof(BlockDesc), hipMemcpyHostToDevice));
+    if (off) PHYS_HIP_TRY(hipMemcpy(d_data.p, data, off * 4, hipMemcpyHostToDevice));
+    if (vec_len) PHYS_HIP_TRY(hipMemcpy(d_vec.p, vec, vec_len * 4, hipMemcpyHostToDevice));
+    PHYS_HIP_TRY(hipMemcpy(d_ptr.p, entry_ptr.data(), (n_out + 1) * 4, hipMemcpyHostToDevice));
+    PHYS_HIP_TRY(hipMemcpy(d_eb.p, entry_blk.data(), entry_blk.size() * 4, hipMemcpyHostToDevice));
+    PHYS_HIP_TRY(hipMemcpy(d_el.p, entry_loc.data(), entry_loc.size() * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_block_spmv, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, nullptr, (uint32_t)n_out, transpose,
+                       reinterpret_cast<const BlockDesc*>(d_blk.p), d_ptr.p, d_eb.p, d_el.p, reinterpret_cast<const float*>(d_data.p),
+                       reinterpret_cast<const float*>(d_vec.p), reinterpret_cast<float*>(d_out.p));
+    PHYS_HIP_TRY(hipGetLastError());
+    PHYS_HIP_TRY(hipMemcpy(out, d_out.p, n_out * 4, hipMemcpyDeviceToHost));
+    return PHYS_OK;
+}

@@ -15,13 +15,15 @@ struct StepParams {
     float dt;
     float g_force[3];   // gravity force (physics.rs:90)
     float g_torque[3];  // offset x force (rigid_body.rs:60), same for every body
+    uint32_t inertia_stride;  // 0: every body shares one diagonal tensor (the reference's only case: identity) - all lanes read
+                              // entry 0 and the 16 bytes per body of the array stay where they are; 1 otherwise
 };
 
 
 // velocity half of RigidBody::step: rigid_body.rs:27, 30-31
 template <bool DIAG>
 __device__ __forceinline__ void integrate_velocity(v3 F, v3 T, float mass, const float* __restrict__ inv_inertia,
-                                                   uint32_t i, float dt, v3& v, v3& w) {
+                                                   uint32_t i, float dt, v3& v, v3& w, uint32_t inertia_stride = 1u) {
     v.x = v.x + F.x / mass * dt;
     v.y = v.y + F.y / mass * dt;
     v.z = v.z + F.z / mass * dt;
@@ -30,7 +32,7 @@ __device__ __forceinline__ void integrate_velocity(v3 F, v3 T, float mass, const
     if (DIAG) {
         // off-diagonals are exactly zero: the gemv row sum reduces to the diagonal product. `inv_inertia` is
         // the compact diagonal array here (one float4 per body)
-        const float4 d = reinterpret_cast<const float4*>(inv_inertia)[i];
+        const float4 d = reinterpret_cast<const float4*>(inv_inertia)[i * inertia_stride];
         dw = v3_make(d.x * L.x, d.y * L.y, d.z * L.z);
     } else {
         m33 I;
@@ -74,10 +76,21 @@ __device__ __forceinline__ void integrate_position(float dt, v3 v, v3 w, v3& x, 
 // One kernel = [apply_gravity] + RigidBody::step for every body.
 // FORCES: read + zero the force/torque accumulators; otherwise they are known to be zero.
 // GRAVITY: fold apply_gravity in (update path); off for a bare phys_step.
+// the quirk-Q3 scatter (physics.rs:45-51): entity 0 alone receives J^T lambda, behind gravity, and only when the CG
+// converged (Some(lambda)); jl / status come from k_constraint_solve of this update, null without constraints
+__device__ __forceinline__ void add_constraint_force(uint32_t i, const float* __restrict__ jl, const uint32_t* __restrict__ cg_status,
+                                                     v3& F, v3& T) {
+    if (jl != nullptr && i == 0u && cg_status[0] != 0u) {
+        F = v3_add(F, v3_make(jl[0], jl[1], jl[2]));
+        T = v3_add(T, v3_make(jl[3], jl[4], jl[5]));
+    }
+}
+
 template <bool FORCES, bool GRAVITY, bool DIAG, bool EXACT_ROT>
 __global__ __launch_bounds__(256) void k_step_full(StepParams sp, float* __restrict__ pos, float* __restrict__ rot,
                                                    float* __restrict__ vel, float* __restrict__ force,
-                                                   float* __restrict__ torque, const float* __restrict__ inv_inertia) {
+                                                   float* __restrict__ torque, const float* __restrict__ inv_inertia,
+                                                   const float* __restrict__ jl, const uint32_t* __restrict__ cg_status) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= sp.n) return;
     v3 F = v3_make(0.0f, 0.0f, 0.0f), T = v3_make(0.0f, 0.0f, 0.0f);
@@ -87,11 +100,12 @@ __global__ __launch_bounds__(256) void k_step_full(StepParams sp, float* __restr
         T = v3_add(T, v3_make(sp.g_torque[0], sp.g_torque[1], sp.g_torque[2]));
         F = v3_add(F, v3_make(sp.g_force[0], sp.g_force[1], sp.g_force[2]));
     }
+    add_constraint_force(i, jl, cg_status, F, T);
     BodyVel bv = ld_vel(vel, i);
     v3 x = ld3(pos, i);
     float4 qq = reinterpret_cast<float4*>(rot)[i];
     quat q; q.i = qq.x; q.j = qq.y; q.k = qq.z; q.w = qq.w;
-    integrate_velocity<DIAG>(F, T, bv.mass, inv_inertia, i, sp.dt, bv.v, bv.w);
+    integrate_velocity<DIAG>(F, T, bv.mass, inv_inertia, i, sp.dt, bv.v, bv.w, sp.inertia_stride);
     integrate_position<EXACT_ROT>(sp.dt, bv.v, bv.w, x, q);
     st_vel(vel, i, bv); st3(pos, i, x);
     reinterpret_cast<float4*>(rot)[i] = make_float4(q.i, q.j, q.k, q.w);
@@ -107,7 +121,8 @@ __global__ __launch_bounds__(256) void k_step_velocity_aabb(StepParams sp, const
                                                             const uint32_t* __restrict__ shape,
                                                             const float* __restrict__ half_extent, float margin,
                                                             float* __restrict__ aabb, StepCounters* __restrict__ ctr,
-                                                            uint4* __restrict__ zero_base, uint32_t zero_count) {
+                                                            uint4* __restrict__ zero_base, uint32_t zero_count,
+                                                            const float* __restrict__ jl, const uint32_t* __restrict__ cg_status) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     // first kernel of the step: it also zeroes the per-step state of the stages behind it (bucket counts,
     // colouring state, counters up to max_extent_bits) instead of a memset launch in front of it
@@ -120,8 +135,9 @@ __global__ __launch_bounds__(256) void k_step_velocity_aabb(StepParams sp, const
             T = v3_add(T, v3_make(sp.g_torque[0], sp.g_torque[1], sp.g_torque[2]));
             F = v3_add(F, v3_make(sp.g_force[0], sp.g_force[1], sp.g_force[2]));
         }
+        add_constraint_force(i, jl, cg_status, F, T);
         BodyVel bv = ld_vel(vel, i);
-        integrate_velocity<DIAG>(F, T, bv.mass, inv_inertia, i, sp.dt, bv.v, bv.w);
+        integrate_velocity<DIAG>(F, T, bv.mass, inv_inertia, i, sp.dt, bv.v, bv.w, sp.inertia_stride);
         st_vel(vel, i, bv);
         if (FORCES) { st3(force, i, v3_make(0.0f, 0.0f, 0.0f)); st3(torque, i, v3_make(0.0f, 0.0f, 0.0f)); }
         const v3 x = ld3(pos, i);
@@ -241,19 +257,23 @@ static inline StepParams make_params(const phys_world* w, float dt) {
     sp.g_torque[0] = o[1] * F[2] - o[2] * F[1];
     sp.g_torque[1] = o[2] * F[0] - o[0] * F[2];
     sp.g_torque[2] = o[0] * F[1] - o[1] * F[0];
+    sp.inertia_stride = (w->all_diag_inertia && w->uniform_inertia) ? 0u : 1u;
     return sp;
 }
 
 static inline dim3 grid_for(uint64_t n) { return dim3((unsigned)((n + 255) / 256)); }
 
 template <bool FORCES, bool GRAVITY>
-static void launch_full(phys_world* w, const StepParams& sp) {
+static void launch_full(phys_world* w, const StepParams& sp, bool with_constraints) {
     const bool diag = w->all_diag_inertia;
     const bool exact = (w->cfg.flags & PHYS_FLAG_EXACT_ROTATION) != 0;
     const dim3 g = grid_for(w->n), b(256);
 #define LAUNCH(D, E)                                                                                              \
     hipLaunchKernelGGL((k_step_full<FORCES, GRAVITY, D, E>), g, b, 0, w->stream, sp, w->pos.p, w->rot.p, w->vel.p, \
-                       w->force.p, w->torque.p, D ? w->inv_inertia_diag.p : w->inv_inertia.p)
+                       w->force.p, w->torque.p, D ? w->inv_inertia_diag.p : w->inv_inertia.p, jl, cg_status)
+    // constraints solved in this update: their force on entity 0 rides along (launch_step_full(.., constraints = true))
+    const float* jl = with_constraints ? w->cg_jl.p : nullptr;
+    const uint32_t* cg_status = with_constraints ? w->cg_status.p : nullptr;
     PHYS_PROF(w, PHYS_STAGE_STEP_FULL);
     if (diag && exact) LAUNCH(true, true);
     else if (diag) LAUNCH(true, false);
@@ -263,15 +283,15 @@ static void launch_full(phys_world* w, const StepParams& sp) {
 }
 
 // gravity (optional) + RigidBody::step for every body, one launch
-void launch_step_full(phys_world* w, float dt, bool gravity) {
+void launch_step_full(phys_world* w, float dt, bool gravity, bool constraints) {
     if (w->n == 0) return;
     const StepParams sp = make_params(w, dt);
-    if (w->forces_dirty) { if (gravity) launch_full<true, true>(w, sp); else launch_full<true, false>(w, sp); }
-    else                 { if (gravity) launch_full<false, true>(w, sp); else launch_full<false, false>(w, sp); }
+    if (w->forces_dirty) { if (gravity) launch_full<true, true>(w, sp, constraints); else launch_full<true, false>(w, sp, constraints); }
+    else                 { if (gravity) launch_full<false, true>(w, sp, constraints); else launch_full<false, false>(w, sp, constraints); }
     w->forces_dirty = false;
 }
 
-void launch_step_velocity_aabb(phys_world* w, float dt, bool gravity, bool zero_step) {
+void launch_step_velocity_aabb(phys_world* w, float dt, bool gravity, bool zero_step, bool constraints) {
     if (w->n == 0) return;
     uint4* zero_base = zero_step ? reinterpret_cast<uint4*>(w->step_zero.p) : nullptr;
     const uint32_t zero_count = zero_step ? (uint32_t)(w->step_zero_reset_bytes / 16) : 0u;
@@ -282,7 +302,9 @@ void launch_step_velocity_aabb(phys_world* w, float dt, bool gravity, bool zero_
 #define LAUNCH(F, G, D)                                                                                            \
     hipLaunchKernelGGL((k_step_velocity_aabb<F, G, D>), g, b, 0, w->stream, sp, w->pos.p, w->rot.p, w->vel.p,      \
                        w->force.p, w->torque.p, D ? w->inv_inertia_diag.p : w->inv_inertia.p, w->shape.p,                \
-                       w->half_extent.p, margin, w->aabb.p, w->counters.p, zero_base, zero_count)
+                       w->half_extent.p, margin, w->aabb.p, w->counters.p, zero_base, zero_count, jl, cg_status)
+    const float* jl = constraints ? w->cg_jl.p : nullptr;
+    const uint32_t* cg_status = constraints ? w->cg_status.p : nullptr;
     const int sel = (w->forces_dirty ? 4 : 0) | (gravity ? 2 : 0) | (diag ? 1 : 0);
     PHYS_PROF(w, PHYS_STAGE_VELOCITY_AABB);
     switch (sel) {

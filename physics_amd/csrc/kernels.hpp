@@ -128,8 +128,8 @@ __device__ __forceinline__ uint32_t cluster_row_owner(uint32_t a, uint32_t home_
 }
 
 // integrate.hip
-void launch_step_full(phys_world* w, float dt, bool gravity);
-void launch_step_velocity_aabb(phys_world* w, float dt, bool gravity, bool zero_step);  // zero_step: also zero the per-step state
+void launch_step_full(phys_world* w, float dt, bool gravity, bool constraints = false);  // constraints: entity 0 += J^T lambda of this update
+void launch_step_velocity_aabb(phys_world* w, float dt, bool gravity, bool zero_step, bool constraints = false);  // zero_step: also zero the per-step state
 void launch_aabb_only(phys_world* w);
 void launch_step_position(phys_world* w, float dt);
 void launch_apply_gravity(phys_world* w);
@@ -154,7 +154,7 @@ void launch_solver(phys_world* w, float dt);
 
 // constraints.hip
 int32_t constraints_alloc(phys_world* w);
-void launch_constraint_phase(phys_world* w);
+void launch_constraint_phase(phys_world* w, bool gravity_pending);  // Q = accumulators (+ gravity when still pending)
 
 // halo.hip
 int32_t halo_pack(phys_world* w, float x_lo, float x_hi, float reach, void* dev_out, uint64_t cap, uint64_t* n_records);

@@ -192,6 +192,7 @@ struct phys_world {
     bool constraints_dirty = false;
     bool have_lambda = false;  // previous_solution.is_some()
     phys::DevBuf<float> cg_x, cg_r, cg_p, cg_ap, cg_rhs, cg_c, cg_scratch;
+    phys::DevBuf<float> cg_jl;         // J^T lambda of entity 0 (6 floats), added by the step kernel behind gravity (quirk Q3)
     phys::DevBuf<uint32_t> cg_status;  // [0] converged flag, [1] iterations, [2] previous_solution.is_some()
     phys::DevBuf<uint32_t> cg_cols;    // col_id | col_ptr | col_rows | row_cidx (constraints.hip)
     uint32_t cg_n_cols = 0;

@@ -239,6 +239,22 @@ class World:
         self._ck(self.lib.phys_halo_exchange(self.h, comm.h))
 
 
+def block_spmv(nrows, ncols, blocks, vec, transpose=False, device=0):
+    """SparseMatrix::multiply_vector / tr_multiply_vector (sparse_matrix.rs:25-50) on the device: `blocks` is the
+    add_block list as (row, column, 2-D array) triples; returns M v (or M^T v) as float32."""
+    lib = _abi.load_library()
+    desc = np.array([[i, j, np.shape(b)[0], np.shape(b)[1]] for i, j, b in blocks], np.uint64).reshape(-1)
+    data = (np.concatenate([np.asarray(b, np.float32).reshape(-1) for _, _, b in blocks]).astype(np.float32)
+            if blocks else np.zeros(0, np.float32))
+    vec = _f(vec).reshape(-1)
+    out = np.zeros(ncols if transpose else nrows, np.float32)
+    rc = lib.phys_block_spmv(device, nrows, ncols, len(blocks), _p(desc, _abi.u64p), _p(data), _p(vec), vec.size,
+                             int(bool(transpose)), _p(out))
+    if rc != 0:
+        raise PhysError(rc, lib.phys_last_error().decode())
+    return out
+
+
 class Comm:
     """One rank of an RCCL communicator behind the C ABI (phys_comm_*): the id travels by whatever the host has."""
 

@@ -124,6 +124,8 @@ extern "C" {
     pub fn phys_get_forces(w: *mut phys_world, force_out: *mut f32, torque_out: *mut f32) -> i32;
     pub fn phys_get_instance_matrices(w: *mut phys_world, out: *mut f32) -> i32;
     pub fn phys_get_lambda(w: *mut phys_world, lambda_out: *mut f32, cap: u64, n_rows: *mut u64) -> i32;
+    pub fn phys_block_spmv(device: i32, nrows: u64, ncols: u64, nblocks: u64, block_desc: *const u64, data: *const f32,
+                           vec: *const f32, vec_len: u64, transpose: i32, out: *mut f32) -> i32;
     pub fn phys_broadphase(w: *mut phys_world, pairs_out: *mut u32, cap: u64, n_pairs: *mut u64) -> i32;
     pub fn phys_get_aabbs(w: *mut phys_world, out: *mut f32) -> i32;
     pub fn phys_get_manifolds(w: *mut phys_world, ids_out: *mut u32, counts_out: *mut u32, normals_out: *mut f32,

@@ -11,6 +11,8 @@ are NOT outputs of the reference. They are:
       warm start, quirk Q4 - from a GENERAL numpy-f32 restatement of update() (class State below).
   G5  the demo scene for 300 frames (quirk Q1 rotation + euler_angles every frame), snapshots at six frames.
   G6  quirk Q3 with three bodies (constraint forces reach entity 0 only), two cases, two frames each.
+  G7  the two GIMBAL branches of euler_angles (fixed_orientation_constraint.rs:17): bodies whose rotation matrix has
+      |r20| >= 1 (pitch = +pi/2 and -pi/2), pinned to an orientation, two frames each.
 Run:  python tests/golden/make_golden.py   (writes the JSON next to this file)
 """
 import json
@@ -180,7 +182,9 @@ def euler_angles(q):
         return [_atan2(r21 / c, r22 / c), pitch, _atan2(r10 / c, r00 / c)]
     if r20 <= f(-1):
         return [_atan2(r01, r02), f(math.pi / 2), f(0)]
-    return [-_atan2(-r01, -r02), f(-math.pi / 2), f(0)]
+    # nalgebra: `(-self[(0, 1)].atan2(-self[(0, 2)]), -FRAC_PI_2, 0)` - a method call binds tighter than the unary minus:
+    # -(r01.atan2(-r02)). (Rounds 1-2 had -atan2(-r01, -r02) here, the opposite sign; no golden reached the branch.)
+    return [-_atan2(r01, -r02), f(-math.pi / 2), f(0)]
 
 
 class State:
@@ -363,10 +367,39 @@ def g6():
     return out
 
 
+def g7():
+    """fixed_orientation_constraint.rs:17 calls UnitQuaternion::euler_angles, whose two gimbal branches (r20 <= -1:
+    pitch = +pi/2, roll = atan2(r01, r02); r20 >= 1: pitch = -pi/2, roll = -atan2(r01, -r02)) no other golden reaches.
+    A pitch of +-pi/2 from from_euler_angles gives |r20| = 0.99999994 in float32 (the regular branch); the quaternion is
+    never renormalised anyway (quirk Q6), so the bodies here carry the quaternion of (roll, +-pi/2, yaw) scaled by
+    1.0625: |r20| = 1.1289 - exactly what a drifted norm does to a body near the pole. Two frames each (the second one
+    starts from the first one's lambda and from a rotated body, back in the regular branch or not)."""
+    dt = as_secs_f32(16_666_667)
+    out = {"dt_nanos": 16_666_667, "cases": []}
+    for pitch, roll, yaw in ((math.pi / 2, 0.3, 0.0), (-math.pi / 2, 0.3, 0.0), (math.pi / 2, -0.7, 0.4), (-math.pi / 2, 1.1, -0.2)):
+        q = [x * f(1.0625) for x in quat_from_euler(roll, pitch, yaw)]
+        bodies = [Body((0.5, 0.25, -0.125), q, 2.0, ang=(0.125, -0.25, 0.5))]
+        cons = [("orientation", 0, (0.1, 0.2, -0.3)), ("point", 0, (0, 0, 0))]
+        i, j, k, w = bodies[0].rot
+        r20 = i * k * f(2) - w * j * f(2)
+        assert abs(r20) >= f(1), r20
+        case = _scene_dict(bodies, cons)
+        case["branch"] = "r20 <= -1 (pitch +pi/2)" if r20 <= f(-1) else "r20 >= 1 (pitch -pi/2)"
+        case["euler0"] = [float(x) for x in euler_angles(bodies[0].rot)]
+        st = State(bodies, cons)
+        case["frames"] = []
+        for _ in range(2):
+            st.update(dt)
+            case["frames"].append(st.snapshot())
+        out["cases"].append(case)
+    assert {c["branch"][:8] for c in out["cases"]} == {"r20 <= -", "r20 >= 1"}
+    return out
+
+
 if __name__ == "__main__":
     out = {"provenance": "hand-derived from the reference source in float32 (numpy), NOT produced by running "
                          "the reference; G3 is data held by the reference's own tests",
-           "G1": g1(), "G2": g2(), "G3": g3(), "G4": g4(), "G5": g5(), "G6": g6()}
+           "G1": g1(), "G2": g2(), "G3": g3(), "G4": g4(), "G5": g5(), "G6": g6(), "G7": g7()}
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference_vectors.json")
     with open(path, "w") as fh:
         json.dump(out, fh, indent=1)

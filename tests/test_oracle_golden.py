@@ -4,7 +4,8 @@ G3 is data held by the reference's own unit tests (sparse_matrix.rs:65-119). G1/
 from the reference source in numpy float32 (the reference cannot be run here: no Rust toolchain), so rows
 A2-A8 stay "parity unpinned" by the reference; these tests guarantee the oracle at least reproduces the
 independent numpy derivation bit for bit - G4: two bodies of unequal mass, 12 constraint rows, multi-iteration
-CG, warm start; G5: the demo scene for 300 frames; G6: quirk Q3 with three bodies."""
+CG, warm start; G5: the demo scene for 300 frames; G6: quirk Q3 with three bodies; G7: the two gimbal branches of
+euler_angles under a fix-orientation constraint."""
 import json
 import os
 
@@ -220,3 +221,21 @@ def test_g6_quirk_q3_three_bodies():
         if c == 0:  # no constraint on body 0: its motion is free fall + gravity torque, whatever lambda was
             lin, _ = w.get_velocities()
             assert lin[0, 0] == 0 and lin[0, 2] == 0
+
+
+def test_g7_gimbal_branches_of_euler_angles():
+    """fixed_orientation_constraint.rs:17 at |r20| >= 1: roll = atan2(r01, r02) with pitch +pi/2, and
+    roll = -(r01.atan2(-r02)) with pitch -pi/2 (the unary minus applies to the method call's result). The oracle's
+    euler_angles itself first, then two frames of update() per case."""
+    g = GOLD2["G7"]
+    seen = set()
+    for c, case in enumerate(g["cases"]):
+        eul = ob.quat_euler_angles(np.array(case["rot0_ijkw"][0], np.float32), ob.TRIG_DET)
+        assert np.array_equal(eul, np.array(case["euler0"], np.float32)), (case["branch"], eul, case["euler0"])
+        seen.add(case["branch"])
+        w = ob.OracleWorld(default_config(), trig=ob.TRIG_DET)
+        load_scene(w, case)
+        for k, frame in enumerate(case["frames"]):
+            w.update(g["dt_nanos"])
+            assert_frame(w, frame, f"G7 case {c} ({case['branch']}) frame {k + 1}")
+    assert len(seen) == 2

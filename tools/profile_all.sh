@@ -2,11 +2,11 @@
 # Round profile collection on the GPU box: for every workload the SAME command three times under rocprofv3 -
 # kernel trace, then the two PMC passes (separate runs: the guide's rule, and gpurun refuses --pmc next to tracing
 # domains other than the kernel trace). tools/profile_window.py then cuts the timed window out of each and writes
-# profiles/r2_<wl>_window.json (run it here, on the merged gpurun_out/).
-#   tools/profile_all.sh c5 t1m c3 c2
+# profiles/r3_<wl>_window.json (run it here, on the merged gpurun_out/).
+#   tools/profile_all.sh c5 t1m c3 c2 c4 t1m_settled ref_1m ref_cg
 set -e
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-out=gpurun_out/prof_r2
+out=gpurun_out/prof_r3
 mkdir -p $out
 for wl in "$@"; do
   args="--workload $wl --warmup 5 --steps 20 --profile-window"

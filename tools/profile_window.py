@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
 """Cut the timed WINDOW out of rocprofv3 runs of `bench.py --workload <wl> --profile-window` and write
-profiles/r2_<wl>_window.json: per kernel the launches, average / min / max duration and (from the two PMC passes)
+profiles/r3_<wl>_window.json: per kernel the launches, average / min / max duration and (from the two PMC passes)
 the HBM traffic per launch, together with the window and the scene state they were taken at - bench.py hands these
 numbers out only for a run of the same window at the same state.
 
     python tools/profile_window.py <wl> <dir with trace_<wl>/, pmc_<wl>_FETCH_SIZE/, pmc_<wl>_WRITE_SIZE/, window_<wl>.json>
 
-A step ends with k_step_position, so the window = everything after the (K+1)-th k_step_position from the end,
+A step ends with k_step_position (k_step_full without the collision stages), so the window = everything after the (K+1)-th k_step_position from the end,
 in dispatch order - the same rule for the kernel trace and for the per-dispatch counter tables.
 Units / corrections (MI355X_MICROARCH.md, HBM): FETCH_SIZE and WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports
 half of the bytes of wide coalesced reads, so traffic = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 bytes per launch.
@@ -27,7 +27,7 @@ def short(name):
 
 def window_rows(rows, k, name_key, order_key):
     rows.sort(key=lambda r: int(r[order_key]))
-    ends = [i for i, r in enumerate(rows) if "k_step_position" in r[name_key]]
+    ends = [i for i, r in enumerate(rows) if "k_step_position" in r[name_key] or "k_step_full" in r[name_key]]
     first = ends[-k - 1] + 1 if len(ends) > k else 0
     return rows[first:ends[-1] + 1]
 
@@ -73,7 +73,7 @@ def main():
             rec["fetch_kib"], rec["write_kib"] = round(fe, 1), round(wr, 1)
             rec["traffic_bytes"] = int((2 * fe + wr) * 1024)
         out["kernels"][name] = rec
-    path = os.path.join(ROOT, "profiles", f"r2_{wl}_window.json")
+    path = os.path.join(ROOT, "profiles", f"r3_{wl}_window.json")
     json.dump(out, open(path, "w"), indent=1)
     print("wrote", path)
     for name, r in list(out["kernels"].items())[:12]:
