@@ -147,16 +147,18 @@ def stats_dict(s):
 class Rig:
     """Everything one rank needs to build its world again and again (one fresh world per repetition)."""
 
-    def __init__(self, workload, rank, world_size, local_rank, dist, rehearsal, sharded):
+    def __init__(self, workload, rank, world_size, local_rank, dist, rehearsal, sharded, strong=False):
         from physics_amd import scenes
         self.workload, self.rank, self.world_size, self.local_rank = workload, rank, world_size, local_rank
         self.dist, self.rehearsal, self.sharded = dist, rehearsal, sharded
+        self.strong = bool(strong and sharded)
         self.halo = None
         if not sharded:
             self.scene = scenes.SCENES[workload]()
         else:
             from physics_amd import sharding
-            self.scene, self.halo = sharding.make_rank_scene(workload, rank, world_size, dist, local_rank, pinned_host=rehearsal)
+            self.scene, self.halo = sharding.make_rank_scene(workload, rank, world_size, dist, local_rank, pinned_host=rehearsal,
+                                                             strong=self.strong)
         self.iters = self.scene.solver_iterations
 
     def make_world(self):
@@ -408,7 +410,7 @@ def measure_workload(rig, args, preroll, reps, with_cpu):
         if s is not None:
             state = s
     med = statistics.median(times)
-    n_total = rig.scene.n * rig.world_size
+    n_total = int(round(rig.sum_over_ranks(float(rig.scene.n))))  # strong scaling: the slabs differ by a body or two
     pairs_total = rig.sum_over_ranks(float(st["n_pairs"] + cross))
     if rig.scene.constraints:
         st["cg_rows"] = 3 * len(rig.scene.constraints)
@@ -421,7 +423,7 @@ def measure_workload(rig, args, preroll, reps, with_cpu):
                         "max_steps_per_sec": round(args.steps / min(times), 2),
                         "every_repetition": "fresh world, same scene, same preroll + warm-up: the same K steps of the same trajectory"},
         "pairs_per_sec": round(pairs_total * args.steps / med, 1),
-        "scene_stats": st, "n_bodies": n_total, "preroll": preroll,
+        "scene_stats": st, "n_bodies": n_total, "preroll": preroll, "cross_pairs_rank": cross,
     }
     if (rig.scene.flags & 1) and not (rig.scene.flags & 8) and st["n_manifolds"] > 0:  # FLAG_COLLISIONS, not broad-phase-only
         sps, slowest = timed_period(rig, preroll, args.warmup)
@@ -463,6 +465,9 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=4, help="timed oracle steps of the CPU sample (bounded by 14 s per variant)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the other single-GPU workloads appended at N=1")
+    ap.add_argument("--weak", action="store_true",
+                    help="--workload c4 --gpus N: N workload-shaped slabs side by side (weak scaling) instead of the ONE 1M-body "
+                         "scene cut into N equal-count slabs (strong scaling, BASELINE config 4: the default for c4)")
     ap.add_argument("--profile-window", action="store_true",
                     help="ONE world, preroll + warm-up + K steps and nothing else: the command the committed rocprofv3 "
                          "kernel-trace / PMC passes run (tools/profile_window.py cuts the last K steps out of the trace)")
@@ -512,7 +517,8 @@ def main():
     n_gpus = world_size
 
     preroll = args.preroll if args.preroll >= 0 else DEFAULT_PREROLL[args.workload]
-    rig = Rig(args.workload, rank, world_size, local_rank, dist, rehearsal, sharded)
+    strong = sharded and args.workload == "c4" and not args.weak
+    rig = Rig(args.workload, rank, world_size, local_rank, dist, rehearsal, sharded, strong=strong)
 
     if args.profile_window:
         w = rig.make_world()
@@ -539,12 +545,18 @@ def main():
         out = {
             "metric": "rigid_body_steps_per_sec", "value": rec["value"],
             "unit": "body-steps/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": rec["ms_per_step"], "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": rec["ms_per_step"], "higher_is_better": True, "scaling": "strong" if rig.strong else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": rig.scene.name, "n_bodies": rec["n_bodies"], "bodies_per_gpu": rig.scene.n,
                        "solver_iterations": rig.iters, "dt_nanos": DT_NANOS, "preroll_steps": preroll,
                        "timed_window": f"steps {preroll + args.warmup}..{preroll + args.warmup + args.steps} of the trajectory",
-                       "sharding": "none" if not sharded else f"x-slabs x{n_gpus}, one process per GPU, halo all-gather per step",
+                       "sharding": "none" if not sharded else (
+                           f"x-slabs x{n_gpus}, one process per GPU; " +
+                           ("ONE scene cut into equal-count slabs (phys_slab_*); " if rig.strong else "one workload-shaped slab per rank; ") +
+                           ("per step: all-gather of fixed-size record blocks over gloo on pinned host buffers (rehearsal)" if rehearsal else
+                            "per step: one grouped ncclSend / ncclRecv pair per slab face with the neighbouring rank (phys_comm_set_neighbours; "
+                            "fixed-size blocks, behind the C ABI: phys_halo_exchange) - exercised with ONE rank only on the builder's "
+                            "one-GPU boxes: unverified with more than 1 rank until the driver's multi-GPU run")),
                        "rccl_ranks": n_gpus if sharded and not rehearsal else (0 if not sharded else f"{n_gpus} (gloo rehearsal on one GPU)")},
             "steps_per_sec": rec["steps_per_sec"], "repetitions": rec["repetitions"],
             "pairs_per_sec": rec["pairs_per_sec"], "scene_stats": rec["scene_stats"],
@@ -569,6 +581,19 @@ def main():
         if "full_period" in rec:
             out["full_period"] = rec["full_period"]
 
+    if rig.strong:
+        # the union over ranks of (local pairs, cross pairs) must equal the pair count of the ONE world holding the whole
+        # scene at the same step (broad-phase-only bodies fall alike on every rank: identical positions, identical AABBs)
+        total_pairs = int(round(rig.sum_over_ranks(float(rec["scene_stats"]["n_pairs"] + rec.get("cross_pairs_rank", 0)))))
+        if rank == 0:
+            single = Rig(args.workload, 0, 1, local_rank, None, False, False)
+            w1 = single.make_world()
+            single.advance(w1, preroll + args.warmup + args.steps)
+            w1.sync()
+            one = int(w1.get_stats().n_pairs)
+            w1.close()
+            out["config"]["pairs_union_check"] = {"sum_over_ranks_local_plus_cross": total_pairs, "single_world": one,
+                                                  "equal": total_pairs == one}
     if rank == 0 and not sharded and not args.no_extra and args.workload == "c5":
         # the other single-GPU configurations, measured the same way (fewer repetitions: they are sub-records)
         others = {}

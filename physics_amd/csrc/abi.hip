@@ -66,6 +66,7 @@ void poll_snapshots(phys_world* w) {
         if (c.overflow) continue;
         w->hint.valid = true;
         w->hint.n_manifolds = c.n_manifolds;
+        w->hint.n_pairs = c.n_pairs;
         w->hint.n_colors = c.n_colors;
         if (c.n_active) w->hint.n_active = c.n_active;  // counted only in the updates that deal out the dynamic homes
         // colouring rounds: a full re-colouring and an incremental update need very different counts, and the
@@ -271,6 +272,7 @@ int32_t phys_set_bodies(phys_world* w, uint64_t n, const float* pos, const float
     if (!w->all_diag_inertia) w->uniform_inertia = false;
     PHYS_HIP_TRY(hipStreamSynchronize(s));  // staging vectors die here
     if (w->cfg.flags & PHYS_FLAG_COLLISIONS) {
+        grid_plan(w, pos, half_extent);
         int32_t rc = collision_alloc(w);
         if (rc != PHYS_OK) return rc;
         if (!(w->cfg.flags & PHYS_FLAG_BROADPHASE_ONLY)) {
@@ -595,7 +597,7 @@ int32_t phys_get_stats(phys_world* w, phys_stats* out) {
     out->overflow = c.overflow | c.sticky_overflow | w->host_sticky_overflow;  // last step's bits + everything since the last phys_sync
     out->n_ground_manifolds = c.n_ground_manifolds;
     std::memcpy(&out->max_extent, &c.max_extent_bits, 4);
-    out->n_halo_records = c.n_halo;
+    out->n_halo_records = c.n_halo + c.n_halo_low;  // both faces of a neighbour exchange
     out->n_cross_pairs = c.n_cross_pairs;
     out->n_ghosts = c.n_ghosts;
     return PHYS_OK;

@@ -24,24 +24,9 @@ namespace phys {
 
 constexpr uint32_t kInvalid = 0xFFFFFFFFu;
 
-// ---- Morton bucket of a cell ----------------------------------------------------------------------
-__device__ __forceinline__ uint32_t part1by2(uint32_t x) {  // spread the low 10 bits 3 apart
-    x &= 0x000003ffu;
-    x = (x ^ (x << 16)) & 0xff0000ffu;
-    x = (x ^ (x << 8)) & 0x0300f00fu;
-    x = (x ^ (x << 4)) & 0x030c30c3u;
-    x = (x ^ (x << 2)) & 0x09249249u;
-    return x;
-}
-__device__ __forceinline__ uint32_t bucket_of_cell(int cx, int cy, int cz, uint32_t axis_mask) {
-    return part1by2((uint32_t)cx & axis_mask) | (part1by2((uint32_t)cy & axis_mask) << 1) |
-           (part1by2((uint32_t)cz & axis_mask) << 2);
-}
-__device__ __forceinline__ int cell_coord(float c, float inv_cell) {
-    float t = floorf(c * inv_cell);
-    t = t < -1.0e9f ? -1.0e9f : (t > 1.0e9f ? 1.0e9f : t);
-    return (int)t;
-}
+// ---- bucket of a cell: kernels.hpp (grid_bucket: brick-major, per-axis sizes) -------------------------------------
+__device__ __forceinline__ uint32_t bucket_of_cell(int cx, int cy, int cz, const GridShape& g) { return grid_bucket(cx, cy, cz, g); }
+__device__ __forceinline__ int cell_coord(float c, float inv_cell) { return grid_cell_coord(c, inv_cell); }
 __device__ __forceinline__ float grid_inv_cell(const StepCounters* ctr) {
     const float ext = __uint_as_float(ctr->max_extent_bits);
     const float cell = ext > 0.0f ? ext * 1.001f : 1.0f;
@@ -50,7 +35,7 @@ __device__ __forceinline__ float grid_inv_cell(const StepCounters* ctr) {
 
 __global__ __launch_bounds__(256) void k_cell_assign(uint32_t n, const float* __restrict__ aabb,
                                                      const uint32_t* __restrict__ shape,
-                                                     const StepCounters* __restrict__ ctr, uint32_t axis_mask,
+                                                     const StepCounters* __restrict__ ctr, GridShape axis_mask,
                                                      uint32_t* __restrict__ bucket_of, uint32_t* __restrict__ rank,
                                                      uint32_t* __restrict__ bucket_count) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -204,7 +189,7 @@ constexpr int kGridSmallBodies = 2;      // per thread: n <= 2048 (10k bodies: 4
 constexpr int kGridSmallBuckets = 4;     // per thread: T <= 4096
 __global__ __launch_bounds__(kGridSmallThreads) void k_grid_small(uint32_t n, const float* __restrict__ aabb,
                                                                   const uint32_t* __restrict__ shape,
-                                                                  const StepCounters* __restrict__ ctr, uint32_t axis_mask,
+                                                                  const StepCounters* __restrict__ ctr, GridShape axis_mask,
                                                                   uint32_t T, uint32_t* bucket_count, uint32_t* bucket_start,
                                                                   uint32_t* __restrict__ sorted_ids,
                                                                   float* __restrict__ sorted_box) {
@@ -301,13 +286,14 @@ __device__ __forceinline__ void stage_flush(PairStage& st, uint32_t* __restrict_
 }
 
 // every lane of the wave calls this together (hit may be false); compacts the hits into the LDS stage
+template <int kStageCap = kStagePerWave>
 __device__ __forceinline__ void stage_push(PairStage& st, bool hit, uint32_t a, uint32_t b,
                                            uint32_t* __restrict__ pairs, uint64_t max_pairs,
                                            StepCounters* __restrict__ ctr) {
     const unsigned long long mask = __ballot(hit);
     if (mask == 0ull) return;
     const uint32_t hits = (uint32_t)__popcll(mask);
-    if (st.count + hits > (uint32_t)kStagePerWave) stage_flush(st, pairs, max_pairs, ctr);
+    if (st.count + hits > (uint32_t)kStageCap) stage_flush(st, pairs, max_pairs, ctr);
     if (hit) {
         const int lane = threadIdx.x & 63;
         const uint32_t r = st.count + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
@@ -321,7 +307,7 @@ __device__ __forceinline__ void stage_push(PairStage& st, bool hit, uint32_t a, 
 // many loads are in flight. The ranges of a lane's cells are fetched up front (independent loads).
 template <int kLanesPerBody>
 __global__ __launch_bounds__(kPairThreads) void k_find_pairs(const uint32_t* __restrict__ bucket_start,
-                                                             uint32_t table_size, uint32_t axis_mask,
+                                                             uint32_t table_size, GridShape axis_mask,
                                                              const uint32_t* __restrict__ sorted_ids,
                                                              const float* __restrict__ sorted_box,
                                                              uint32_t* __restrict__ pairs, uint64_t max_pairs,
@@ -390,6 +376,151 @@ __global__ __launch_bounds__(kPairThreads) void k_find_pairs(const uint32_t* __r
     stage_flush(st, pairs, max_pairs, ctr);
 }
 
+// ---- candidate pairs, one workgroup per BRICK of the grid ------------------------------------------------------------
+// k_find_pairs above walks, per body, 14 cells x (bucket range -> candidates) as dependent loads through the L2: 204 us
+// for 1M bodies (C4), 2 % of the HBM rate, and 6.2x the compulsory traffic, because the lanes of a workgroup sit on
+// eight XCDs' worth of unrelated cells and every L2 ends up fetching most of the boxes. Here a workgroup owns one brick
+// of 4 x 4 x 4 cells - 64 consecutive buckets, so its bodies are ONE run of the bucket-sorted arrays - and first stages
+// what its bodies can meet: the 6 x 6 x 5 cells of the brick and its half-shell halo (x, y from -1 to 4, z from 0 to 4):
+//   1. 180 lanes fetch the bucket ranges of the region's cells (one round trip), a scan turns the counts into LDS offsets;
+//   2. all lanes copy the region's {box, id} records into LDS (second round trip; 28 bytes each, every record of the
+//      region exactly once per brick = 2.8 records staged per body);
+//   3. four lanes per own body walk the body's 14 cells in LDS; hits go through the same ballot / popcount stage.
+// The chain a body waits for is two global round trips per BRICK instead of 28 per body. A region with more records
+// than the stage holds (a scene far denser than its grid) is walked in global memory as before - same code path, the
+// cell table then holds positions in the sorted arrays instead of in LDS. Bricks are dealt so that the workgroups of one
+// XCD (blockIdx % 8) cover one contiguous eighth of the table: a box is fetched into ONE L2, and again only by the
+// neighbour XCDs along the eighth's two faces. Same pair SET as k_find_pairs (each pair found by the body whose cell
+// comes first in the half-shell order; own-cell pairs by id order).
+constexpr int kRegX = 6, kRegY = 6, kRegZ = 5, kRegCells = kRegX * kRegY * kRegZ;  // 180
+constexpr int kBrickLanesPerBody = 4;
+constexpr int kBrickStagePerWave = 256;  // pairs staged per wave before a flush (2 KiB)
+
+template <int CAP /* records staged per brick */>
+__global__ __launch_bounds__(kPairThreads) void k_find_pairs_brick(const uint32_t* __restrict__ bucket_start, uint32_t n_bricks,
+                                                                   GridShape g, const uint32_t* __restrict__ sorted_ids,
+                                                                   const float* __restrict__ sorted_box,
+                                                                   uint32_t* __restrict__ pairs, uint64_t max_pairs,
+                                                                   StepCounters* __restrict__ ctr) {
+    __shared__ uint32_t stage[(kPairThreads / 64) * kBrickStagePerWave * 2];
+    __shared__ uint32_t s_gstart[kRegCells];    // position of a region cell's first record in the sorted arrays
+    __shared__ uint32_t s_off[kRegCells + 1];   // exclusive scan of the cells' record counts (position in s_rec)
+    __shared__ float s_rec[CAP * 7];            // {lo xyz, hi xyz, id}: odd stride, distinct banks for neighbouring records
+    __shared__ uint32_t s_wsum[4];
+    // XCD-aware deal (a label, never relied on for correctness): workgroups with equal blockIdx % 8 share an L2
+    uint32_t brick = blockIdx.x;
+    if (n_bricks >= 8u && gridDim.x == n_bricks) brick = (blockIdx.x & 7u) * (n_bricks >> 3) + (blockIdx.x >> 3);
+    if (brick >= n_bricks) return;
+    const uint32_t own_begin = bucket_start[brick * 64u], own_end = bucket_start[brick * 64u + 64u];
+    if (own_begin == own_end) return;  // workgroup-uniform: an empty brick
+    PairStage st;
+    st.lds = stage + (threadIdx.x >> 6) * kBrickStagePerWave * 2;
+    st.count = 0;
+    const uint32_t bx = brick & ((1u << g.sx) - 1u), by = (brick >> g.sx) & ((1u << g.sy) - 1u), bz = brick >> (g.sx + g.sy);
+    const uint32_t ox = bx << 2, oy = by << 2, oz = bz << 2;
+    // 1. bucket ranges of the region's cells, scanned
+    {
+        uint32_t cnt = 0;
+        if (threadIdx.x < (uint32_t)kRegCells) {
+            const uint32_t r = threadIdx.x;
+            const uint32_t rx = r % kRegX, ry = (r / kRegX) % kRegY, rz = r / (kRegX * kRegY);
+            const uint32_t bk = grid_bucket_masked((ox + rx - 1u) & g.mx, (oy + ry - 1u) & g.my, (oz + rz) & g.mz, g);
+            const uint32_t b0 = bucket_start[bk], b1 = bucket_start[bk + 1];
+            s_gstart[r] = b0;
+            cnt = b1 - b0;
+        }
+        const uint32_t inc = wave_inclusive_scan(cnt);
+        if ((threadIdx.x & 63u) == 63u) s_wsum[threadIdx.x >> 6] = inc;
+        __syncthreads();
+        uint32_t base = 0;
+        for (uint32_t k = 0; k < (threadIdx.x >> 6); ++k) base += s_wsum[k];
+        if (threadIdx.x < (uint32_t)kRegCells) s_off[threadIdx.x] = base + inc - cnt;
+        if (threadIdx.x == (uint32_t)kRegCells - 1u) s_off[kRegCells] = base + inc;
+        __syncthreads();
+    }
+    const uint32_t total = s_off[kRegCells];
+    const bool staged = total <= (uint32_t)CAP;
+    // 2. the region's records into LDS
+    if (staged) {
+        for (uint32_t q = threadIdx.x; q < total; q += kPairThreads) {
+            uint32_t lo = 0, hi = kRegCells;  // the cell r with s_off[r] <= q < s_off[r + 1]
+            while (hi - lo > 1u) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (s_off[mid] <= q) lo = mid; else hi = mid;
+            }
+            const uint32_t t = s_gstart[lo] + (q - s_off[lo]);
+            const v3 blo = ld3(sorted_box, 2 * t), bhi = ld3(sorted_box, 2 * t + 1);
+            float* rec = s_rec + 7u * q;
+            rec[0] = blo.x; rec[1] = blo.y; rec[2] = blo.z; rec[3] = bhi.x; rec[4] = bhi.y; rec[5] = bhi.z;
+            rec[6] = __uint_as_float(sorted_ids[t]);
+        }
+        __syncthreads();
+    }
+    // 3. the brick's own bodies, four lanes each, against the 14 cells of their half shell
+    const float inv_cell = grid_inv_cell(ctr);
+    const uint32_t n_own = own_end - own_begin;
+    const uint32_t sub = threadIdx.x % kBrickLanesPerBody;
+    constexpr uint32_t kBodiesPerTrip = kPairThreads / kBrickLanesPerBody;
+    for (uint32_t base = 0; base < n_own; base += kBodiesPerTrip) {
+        const uint32_t jo = base + threadIdx.x / kBrickLanesPerBody;
+        const bool live = jo < n_own;
+        uint32_t i = 0;
+        aabb_t bi;
+        bi.lo = v3_make(0, 0, 0); bi.hi = v3_make(0, 0, 0);
+        uint32_t lx = 0, ly = 0, lz = 0;
+        if (live) {
+            const uint32_t sidx = own_begin + jo;
+            i = sorted_ids[sidx];
+            bi.lo = ld3(sorted_box, 2 * sidx);
+            bi.hi = ld3(sorted_box, 2 * sidx + 1);
+            // the brick's origin is a multiple of four cells on every axis: the low two bits are the place in the brick
+            lx = (uint32_t)cell_coord(0.5f * (bi.lo.x + bi.hi.x), inv_cell) & 3u;
+            ly = (uint32_t)cell_coord(0.5f * (bi.lo.y + bi.hi.y), inv_cell) & 3u;
+            lz = (uint32_t)cell_coord(0.5f * (bi.lo.z + bi.hi.z), inv_cell) & 3u;
+        }
+#pragma unroll
+        for (int k = 0; k < (14 + kBrickLanesPerBody - 1) / kBrickLanesPerBody; ++k) {
+            const int c = (int)sub + kBrickLanesPerBody * k;
+            int dx, dy, dz;  // half shell: own cell (c = 0) + the 13 cells with (dz, dy, dx) > (0, 0, 0) lexicographically
+            if (c == 0) { dx = 0; dy = 0; dz = 0; }
+            else if (c == 1) { dx = 1; dy = 0; dz = 0; }
+            else if (c < 5) { dx = c - 3; dy = 1; dz = 0; }
+            else { dx = (c - 5) % 3 - 1; dy = ((c - 5) / 3) % 3 - 1; dz = 1; }
+            uint32_t t = 0, t_end = 0;
+            if (live && c < 14) {
+                const uint32_t rid = ((lz + (uint32_t)dz) * kRegY + (ly + (uint32_t)(dy + 1))) * kRegX + (lx + (uint32_t)(dx + 1));
+                const uint32_t o0 = s_off[rid], o1 = s_off[rid + 1];
+                t = staged ? o0 : s_gstart[rid];
+                t_end = t + (o1 - o0);
+            }
+            const bool own_cell = c == 0;
+            while (__any(t < t_end)) {
+                bool hit = false;
+                uint32_t j = 0;
+                if (t < t_end) {
+                    aabb_t bj;
+                    if (staged) {
+                        const float* rec = s_rec + 7u * t;
+                        bj.lo = v3_make(rec[0], rec[1], rec[2]);
+                        bj.hi = v3_make(rec[3], rec[4], rec[5]);
+                        j = __float_as_uint(rec[6]);
+                    } else {
+                        j = sorted_ids[t];
+                        bj.lo = ld3(sorted_box, 2 * t);
+                        bj.hi = ld3(sorted_box, 2 * t + 1);
+                    }
+                    // own cell: each unordered pair once by id order. Other cells: a bucket can alias a far cell
+                    // (wrap-around); such a candidate fails the overlap test, and the 14 buckets are distinct.
+                    hit = aabb_overlap(bi, bj) && (!own_cell || i < j);
+                    ++t;
+                }
+                stage_push<kBrickStagePerWave>(st, hit, i < j ? i : j, i < j ? j : i, pairs, max_pairs, ctr);
+            }
+        }
+    }
+    stage_flush(st, pairs, max_pairs, ctr);
+}
+
 // ---- slot grid (small scenes) ------------------------------------------------------------------------
 // With a table of >= 2 buckets per body almost every bucket holds 0-2 bodies: instead of counting, scanning and
 // scattering (three dependent launches) a body simply takes one of EIGHT slots of its bucket (id + box) and the
@@ -400,7 +531,7 @@ constexpr uint32_t kSlotGridMaxBodies = 32768;  // beyond, streaming the sorted 
 
 __global__ __launch_bounds__(256) void k_cell_insert(uint32_t n, const float* __restrict__ aabb,
                                                      const uint32_t* __restrict__ shape, StepCounters* __restrict__ ctr,
-                                                     uint32_t axis_mask, uint32_t* __restrict__ rank,
+                                                     GridShape axis_mask, uint32_t* __restrict__ rank,
                                                      uint32_t* __restrict__ bucket_count, uint32_t* __restrict__ slot_ids,
                                                      float* __restrict__ slot_box, uint32_t* __restrict__ ovf) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -430,7 +561,7 @@ __global__ __launch_bounds__(kPairThreads) void k_find_pairs_slots(uint32_t n, c
                                                                    const uint32_t* __restrict__ bucket_count,
                                                                    const uint32_t* __restrict__ slot_ids,
                                                                    const float* __restrict__ slot_box,
-                                                                   const uint32_t* __restrict__ ovf, uint32_t axis_mask,
+                                                                   const uint32_t* __restrict__ ovf, GridShape axis_mask,
                                                                    uint32_t* __restrict__ pairs, uint64_t max_pairs,
                                                                    StepCounters* __restrict__ ctr) {
     constexpr int kCellsPerLane = (14 + kLanesPerBody - 1) / kLanesPerBody;
@@ -511,10 +642,46 @@ __global__ __launch_bounds__(kPairThreads) void k_find_pairs_slots(uint32_t n, c
 }
 
 // ---- host side -------------------------------------------------------------------------------------
-static uint32_t table_size_for(uint64_t n) {
-    uint32_t t = 512;  // 8^3
-    while ((uint64_t)t < 2 * n && t < (1u << 27)) t <<= 3;  // powers of 8: equal Morton bits per axis
-    return t;
+static uint32_t table_bits_for(uint64_t n) {
+    uint32_t bits = 9;  // 512 buckets = 8 bricks at least
+    while ((1ull << bits) < 2 * n && bits < 27) ++bits;
+    return bits;
+}
+
+// Table size (>= 2 buckets per body, a power of two) and its split over the axes, from the scene as uploaded: every axis
+// starts with 2 bits (one brick of 4 cells) and the rest go, one at a time, to the axis with the most cells per bucket
+// row - cells estimated as extent of the body centres / the largest bounding diameter. Any split is correct (cells wrap
+// modulo the axis size); a good one keeps far-apart cells out of the same bucket. Bodies move, the split stays: a pile
+// that compresses or spreads by a factor of two costs one bit of accuracy, not correctness.
+void grid_plan(phys_world* w, const float* pos, const float* half_extent) {
+    const uint64_t n = w->n_owned;
+    const uint32_t bits = table_bits_for(w->n);
+    w->grid_table_size = 1u << bits;
+    float lo[3] = {3e38f, 3e38f, 3e38f}, hi[3] = {-3e38f, -3e38f, -3e38f}, diam = 0.0f;
+    for (uint64_t i = 0; i < n; ++i) {
+        for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], pos[3 * i + a]); hi[a] = std::max(hi[a], pos[3 * i + a]); }
+        if (half_extent) {
+            const float* h = half_extent + 3 * i;
+            diam = std::max(diam, 2.0f * std::max(h[0], std::max(h[1], h[2])));
+        }
+    }
+    const float cell = (diam > 0.0f ? diam : 1.0f) * 1.05f + 2.0f * w->cfg.contact_margin;
+    double cells[3];
+    for (int a = 0; a < 3; ++a) cells[a] = n ? std::max(1.0, (double)(hi[a] - lo[a]) / cell + 1.0) : 1.0;
+    uint32_t ab[3] = {2, 2, 2};
+    for (uint32_t left = bits - 6; left > 0; --left) {
+        int best = 0;
+        double worst = -1.0;
+        for (int a = 0; a < 3; ++a) {
+            const double load = cells[a] / (double)(1u << ab[a]);
+            if (load > worst && ab[a] < 20) { worst = load; best = a; }
+        }
+        ab[best] += 1;
+    }
+    GridShape g;
+    g.mx = (1u << ab[0]) - 1u; g.my = (1u << ab[1]) - 1u; g.mz = (1u << ab[2]) - 1u;
+    g.sx = ab[0] - 2u; g.sy = ab[1] - 2u;
+    w->grid_shape = g;
 }
 
 int32_t collision_alloc(phys_world* w) {
@@ -525,8 +692,7 @@ int32_t collision_alloc(phys_world* w) {
         set_error("max_pairs / max_manifolds exceed u32 indexing");
         return PHYS_ERR_INVALID_ARG;
     }
-    w->grid_table_size = table_size_for(n);
-    const uint32_t T = w->grid_table_size;
+    const uint32_t T = w->grid_table_size;  // grid_plan (phys_set_bodies), before this
     {
         // one allocation, zeroed by one memset per step: [bucket counts | colouring state | StepCounters]
         const size_t b_bytes = ((size_t)T * 4 + 255) / 256 * 256;
@@ -613,17 +779,13 @@ void zero_step_state(phys_world* w, bool including_extent) {
     (void)hipMemsetAsync(w->step_zero.p, 0, including_extent ? w->step_zero_full_bytes : w->step_zero_reset_bytes, w->stream);
 }
 
-static uint32_t grid_axis_mask(const phys_world* w) {
-    uint32_t bits = 0;
-    while ((1u << (3 * bits)) < w->grid_table_size) ++bits;
-    return (1u << bits) - 1u;
-}
+static GridShape grid_axis_mask(const phys_world* w) { return w->grid_shape; }
 
 // bucket_start / sorted_ids / sorted_box from the current AABBs; the bucket counts must be zero
 void build_sorted_grid(phys_world* w) {
     const uint32_t n = (uint32_t)w->n;
     const uint32_t T = w->grid_table_size;
-    const uint32_t axis_mask = grid_axis_mask(w);
+    const GridShape axis_mask = grid_axis_mask(w);
     hipStream_t s = w->stream;
     const dim3 gb((n + 255) / 256), tb(256);
     w->sorted_grid_valid = true;
@@ -654,7 +816,7 @@ void launch_broadphase(phys_world* w) {
     if (n == 0) return;
     w->grid_valid = true;
     const uint32_t T = w->grid_table_size;
-    const uint32_t axis_mask = grid_axis_mask(w);
+    const GridShape axis_mask = grid_axis_mask(w);
     hipStream_t s = w->stream;
     if (n <= kSlotGridMaxBodies) {
         // slot grid: two launches for the whole broad phase
@@ -672,6 +834,22 @@ void launch_broadphase(phys_world* w) {
     // throughput-bound: one lane per body does the least total work
     static const int pair_lanes_env = getenv("PHYS_DEBUG_PAIR_LANES") ? atoi(getenv("PHYS_DEBUG_PAIR_LANES")) : 0;  // measurements
     // (measured: one lane per body is the faster one already at 100k bodies - C3: 0.051 against 0.089 ms)
+    // PHYS_DEBUG_PAIR_KERNEL=body: the one-lane-(or four)-per-body kernels of rounds 1-2 (A/B measurements; same pair set)
+    static const bool body_kernel = getenv("PHYS_DEBUG_PAIR_KERNEL") != nullptr && getenv("PHYS_DEBUG_PAIR_KERNEL")[0] == 'b';
+    if (!body_kernel && !pair_lanes_env) {
+        const uint32_t n_bricks = T >> 6;
+        // records staged per brick: 640 (28 KiB of LDS per workgroup, five per CU) covers lattices and falling piles; scenes
+        // with many pairs per body (resting piles of rotated boxes: big cells, several bodies each) take the larger stage
+        const bool dense = w->hint.valid && (uint64_t)w->hint.n_pairs > 5ull * w->n;
+        PHYS_PROF(w, PHYS_STAGE_PAIRS);
+        if (dense)
+            hipLaunchKernelGGL((k_find_pairs_brick<2048>), dim3(n_bricks), dim3(kPairThreads), 0, s, w->bucket_start.p, n_bricks, axis_mask,
+                               w->sorted_ids.p, w->sorted_box.p, w->pairs.p, w->max_pairs, w->counters.p);
+        else
+            hipLaunchKernelGGL((k_find_pairs_brick<640>), dim3(n_bricks), dim3(kPairThreads), 0, s, w->bucket_start.p, n_bricks, axis_mask,
+                               w->sorted_ids.p, w->sorted_box.p, w->pairs.p, w->max_pairs, w->counters.p);
+        return;
+    }
     if (pair_lanes_env ? pair_lanes_env == 4 : n <= 65536u) {
         PHYS_PROF(w, PHYS_STAGE_PAIRS);
         hipLaunchKernelGGL((k_find_pairs<4>), dim3((unsigned)(((uint64_t)n * 4 + kPairThreads - 1) / kPairThreads)), dim3(kPairThreads), 0, s,

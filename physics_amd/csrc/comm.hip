@@ -125,6 +125,7 @@ static int32_t exchange_front(phys_world* w, phys_comm* c, size_t* bytes_per_ran
     const size_t rec = ghosts ? (size_t)PHYS_HALO_BODY_RECORD_BYTES : (size_t)32;
     *bytes_per_rank = c->cap * rec;
     if (!c->neighbours) {
+        PHYS_HIP_TRY(hipMemsetAsync(&w->counters.p->n_halo_low, 0, 4, w->stream));
         if (ghosts) return halo_pack_bodies(w, c->send, c->cap);
         return halo_pack(w, w->slab_lo, w->slab_hi, w->slab_reach, c->send, c->cap, nullptr);
     }
@@ -136,6 +137,12 @@ static int32_t exchange_front(phys_world* w, phys_comm* c, size_t* bytes_per_ran
     if (c->rank > 0)
         rc = ghosts ? halo_pack_bodies_faces(w, send, c->cap, w->slab_lo, far)
                     : halo_pack(w, w->slab_lo, far, w->slab_reach, send, c->cap, nullptr);
+    // the count of the low-face block survives the packing of the high-face one (phys_stats.n_halo_records = both)
+    if (c->rank > 0 && rc == PHYS_OK)
+        PHYS_HIP_TRY(hipMemcpyAsync(&w->counters.p->n_halo_low, &w->counters.p->n_halo, 4, hipMemcpyDeviceToDevice, w->stream));
+    else
+        PHYS_HIP_TRY(hipMemsetAsync(&w->counters.p->n_halo_low, 0, 4, w->stream));
+    if (c->rank + 1 >= c->n_ranks) PHYS_HIP_TRY(hipMemsetAsync(&w->counters.p->n_halo, 0, 4, w->stream));  // no high face: its count is 0
     if (rc == PHYS_OK && c->rank + 1 < c->n_ranks)
         rc = ghosts ? halo_pack_bodies_faces(w, send + block, c->cap, -far, w->slab_hi)
                     : halo_pack(w, -far, w->slab_hi, w->slab_reach, send + block, c->cap, nullptr);

@@ -22,22 +22,8 @@ struct HaloRecord {
 };
 static_assert(sizeof(HaloRecord) == 32, "halo record is 32 bytes");
 
-__device__ __forceinline__ uint32_t part1by2h(uint32_t x) {
-    x &= 0x000003ffu;
-    x = (x ^ (x << 16)) & 0xff0000ffu;
-    x = (x ^ (x << 8)) & 0x0300f00fu;
-    x = (x ^ (x << 4)) & 0x030c30c3u;
-    x = (x ^ (x << 2)) & 0x09249249u;
-    return x;
-}
-__device__ __forceinline__ uint32_t bucket_h(int cx, int cy, int cz, uint32_t m) {
-    return part1by2h((uint32_t)cx & m) | (part1by2h((uint32_t)cy & m) << 1) | (part1by2h((uint32_t)cz & m) << 2);
-}
-__device__ __forceinline__ int cell_h(float c, float inv_cell) {
-    float t = floorf(c * inv_cell);
-    t = t < -1.0e9f ? -1.0e9f : (t > 1.0e9f ? 1.0e9f : t);
-    return (int)t;
-}
+__device__ __forceinline__ uint32_t bucket_h(int cx, int cy, int cz, const GridShape& g) { return grid_bucket(cx, cy, cz, g); }
+__device__ __forceinline__ int cell_h(float c, float inv_cell) { return grid_cell_coord(c, inv_cell); }
 
 __global__ __launch_bounds__(256) void k_halo_pack(uint32_t n, const float* __restrict__ aabb,
                                                    const uint32_t* __restrict__ shape,
@@ -99,7 +85,7 @@ template <bool SLOTS>
 __global__ __launch_bounds__(256) void k_halo_pairs(uint32_t n_remote, uint32_t skip_first, uint32_t skip_count,
                                                     const HaloRecord* __restrict__ remote,
                                                     const uint32_t* __restrict__ bucket_start, uint32_t table_size,
-                                                    uint32_t axis_mask, const uint32_t* __restrict__ sorted_ids,
+                                                    GridShape axis_mask, const uint32_t* __restrict__ sorted_ids,
                                                     const float* __restrict__ sorted_box,
                                                     const uint32_t* __restrict__ ovf, const float* __restrict__ aabb,
                                                     const uint32_t* __restrict__ global_id,
@@ -123,7 +109,8 @@ __global__ __launch_bounds__(256) void k_halo_pairs(uint32_t n_remote, uint32_t 
         for (int a = 0; a < 3; ++a) {
             c0[a] = cell_h(r.lo[a] - 0.5f * cell, inv_cell);
             c1[a] = cell_h(r.hi[a] + 0.5f * cell, inv_cell);
-            if (c1[a] - c0[a] > 7) c1[a] = c0[a] + 7;  // a remote box spanning > 8 cells would alias the table
+            if (c1[a] - c0[a] > 7) c1[a] = c0[a] + 7;  // bound of the sweep (a remote box is at most `reach` wide; buckets met twice on
+                                                       // a short axis are harmless: a candidate counts only in its TRUE cell, below)
         }
     }
     // wave-uniform sweep over the largest cell range in the wave
@@ -406,18 +393,16 @@ int32_t halo_pairs(phys_world* w, const void* dev_remote, uint64_t n_remote, uin
     PHYS_HIP_TRY(hipMemsetAsync(&w->counters.p->n_cross_pairs, 0, 4, w->stream));
     if (n_remote && w->n) {
         const uint32_t T = w->grid_table_size;
-        uint32_t bits = 0;
-        while ((1u << (3 * bits)) < T) ++bits;
         PHYS_PROF(w, PHYS_STAGE_MISC);
         if (w->sorted_grid_valid)
             hipLaunchKernelGGL(k_halo_pairs<false>, dim3((unsigned)((n_remote + 255) / 256)), dim3(256), 0, w->stream,
                                (uint32_t)n_remote, (uint32_t)skip_first, (uint32_t)skip_count, (const HaloRecord*)dev_remote, w->bucket_start.p, T,
-                               (1u << bits) - 1u, w->sorted_ids.p, w->sorted_box.p, nullptr, w->aabb.p, w->global_id.p, w->cross_pairs.p,
+                               w->grid_shape, w->sorted_ids.p, w->sorted_box.p, nullptr, w->aabb.p, w->global_id.p, w->cross_pairs.p,
                                w->max_cross_pairs, w->counters.p);
         else  // the slot grid of small scenes
             hipLaunchKernelGGL(k_halo_pairs<true>, dim3((unsigned)((n_remote + 255) / 256)), dim3(256), 0, w->stream,
                                (uint32_t)n_remote, (uint32_t)skip_first, (uint32_t)skip_count, (const HaloRecord*)dev_remote, w->bucket_count.p, T,
-                               (1u << bits) - 1u, w->slot_ids.p, w->slot_box.p, w->grid_ovf.p, w->aabb.p, w->global_id.p, w->cross_pairs.p,
+                               w->grid_shape, w->slot_ids.p, w->slot_box.p, w->grid_ovf.p, w->aabb.p, w->global_id.p, w->cross_pairs.p,
                                w->max_cross_pairs, w->counters.p);
     }
     if (!n_cross) return PHYS_OK;  // asynchronous form

@@ -112,6 +112,29 @@ __device__ __forceinline__ void color_table_insert(const ColorTableJob& job, uin
     }
 }
 
+// ---- uniform grid of the broad phase: cell -> bucket -----------------------------------------------------------------
+// The table has 2^bits buckets, bits = bx + by + bz split over the axes in proportion to the scene's extent (a tower 16
+// cells wide and 980 high gets x 4, y 10, z 5 instead of 7 + 7 + 7: with equal bits its 128-cell axis wrapped 7.6 times
+// and every bucket held the bodies of eight different cells). Cell coordinates are taken modulo the axis size (far
+// bodies alias; aliased candidates fail the overlap test, and neighbouring cells never alias: every axis has >= 4 cells).
+// Buckets are numbered BRICK-major: a brick is 4 x 4 x 4 cells = 64 consecutive buckets (the low two bits of each
+// coordinate interleaved), bricks x-fastest. So the bodies of a brick are one contiguous run of the bucket-sorted
+// arrays, which is what lets one workgroup stage a brick and its half-shell halo in LDS (k_find_pairs_brick).
+// (struct GridShape: world.hpp)
+__host__ __device__ __forceinline__ uint32_t grid_bucket_masked(uint32_t x, uint32_t y, uint32_t z, const GridShape& g) {
+    const uint32_t brick = ((((z >> 2) << g.sy) | (y >> 2)) << g.sx) | (x >> 2);
+    const uint32_t local = (x & 1u) | ((y & 1u) << 1) | ((z & 1u) << 2) | ((x & 2u) << 2) | ((y & 2u) << 3) | ((z & 2u) << 4);
+    return (brick << 6) | local;
+}
+__host__ __device__ __forceinline__ uint32_t grid_bucket(int cx, int cy, int cz, const GridShape& g) {
+    return grid_bucket_masked((uint32_t)cx & g.mx, (uint32_t)cy & g.my, (uint32_t)cz & g.mz, g);
+}
+__device__ __forceinline__ int grid_cell_coord(float c, float inv_cell) {
+    float t = floorf(c * inv_cell);
+    t = t < -1.0e9f ? -1.0e9f : (t > 1.0e9f ? 1.0e9f : t);
+    return (int)t;
+}
+
 // Cluster solver: which cluster's workgroup owns a row. A body has a HOME cluster (cluster_slot / slots) or none (ghost
 // bodies of a sharded world; bodies beyond the capacity of a dynamic clustering). A row is owned by the home of its
 // body A, else by the home of its body B, else - both homeless - by a cluster picked from A's id. A side whose body's
@@ -138,6 +161,7 @@ void launch_instance_matrices(phys_world* w, float* d_out);
 
 // broadphase.hip
 int32_t collision_alloc(phys_world* w);
+void grid_plan(phys_world* w, const float* host_pos, const float* host_half_extent);  // table size and its split over the axes
 void zero_step_state(phys_world* w, bool including_extent);  // ONE memset: counters + bucket counts + colouring state
 void launch_broadphase(phys_world* w);
 void build_sorted_grid(phys_world* w);  // bucket_start / sorted_ids / sorted_box from the current AABBs (bucket counts zeroed)

@@ -852,6 +852,7 @@ void launch_coloring(phys_world* w) {
         if (!c.overflow) {
             w->hint.valid = true;
             w->hint.n_manifolds = c.n_manifolds;
+            w->hint.n_pairs = c.n_pairs;
             w->hint.n_colors = c.n_colors;
             if (c.n_active) w->hint.n_active = c.n_active;
             if (full) w->hint.full_rounds = c.color_rounds; else w->hint.color_rounds = c.color_rounds;

@@ -91,6 +91,7 @@ struct StepCounters {
     // neither the per-step reset nor the extent restart (both stop short of it).
     uint32_t sticky_overflow;
     uint32_t n_ghosts;   // ghost slots filled by the last phys_halo_unpack_ghosts (set before the update: not part of the per-step reset)
+    uint32_t n_halo_low; // neighbour exchange: records of the LOW-face block (n_halo then counts the high-face block; the stats add them)
     uint32_t debug[8];  // what a kernel that refused a corrupt row saw (overflow bit 5); never read by device code
 };
 constexpr size_t kCountersStepResetBytes = offsetof(StepCounters, max_extent_bits);
@@ -144,13 +145,19 @@ struct ProfScope {
 // correctness
 struct StepHint {
     bool valid = false;
-    uint32_t n_manifolds = 0, n_colors = 0;
+    uint32_t n_manifolds = 0, n_colors = 0, n_pairs = 0;
     uint32_t n_active = 0;         // owned bodies with a manifold (0 = unknown)
     uint32_t color_rounds = 0;     // max over the recent INCREMENTAL updates
     uint32_t full_rounds = 0;      // rounds of the last full re-colouring (0 = unknown)
     uint32_t recent_rounds[8] = {};
     uint32_t recent_pos = 0;
     uint32_t color_count[kMaxColors] = {};
+};
+
+// split of the broad phase's bucket table over the three axes (kernels.hpp: grid_bucket)
+struct GridShape {
+    uint32_t mx = 7, my = 7, mz = 7;  // per-axis masks: cells per axis - 1 (each >= 3)
+    uint32_t sx = 1, sy = 1;          // bits of the brick coordinates along x and y (= axis bits - 2)
 };
 
 // worlds alive per device in this process (abi.hip): two of them step on two streams, i.e. beside each other
@@ -202,6 +209,7 @@ struct phys_world {
     // collision pipeline (A10-A12)
     uint64_t max_pairs = 0, max_manifolds = 0;
     uint32_t grid_table_size = 0;  // hashed-grid buckets (power of two)
+    phys::GridShape grid_shape{};  // its split over the three axes (kernels.hpp GridShape; set by grid_plan)
     // counters, bucket_count and color_state are windows into ONE allocation (step_zero) laid out
     // [bucket counts | colouring state | StepCounters], so one memset per step zeroes all three (up to, not
     // including, StepCounters::max_extent_bits at the very end)

@@ -89,6 +89,26 @@ def rank_scene(workload, rank, world_size, shape=None):
     return sc, float(x_lo), float(x_hi), gids
 
 
+def strong_rank_scene(workload, rank, world_size, bins=4096, scene=None):
+    """STRONG scaling (BASELINE.json config 4: "1M bodies ... sharded across 8 x MI355X"): ONE scene cut into world_size
+    equal-count x-slabs - histogram of body x -> prefix sums -> cut planes (phys_slab_*); every rank
+    derives the same planes from the same scene and keeps the bodies of its slab under their ids of the whole scene.
+    Returns (scene of this rank, x_lo, x_hi, global ids, bodies of the whole scene)."""
+    full = scene if scene is not None else scenes.SCENES[workload]()
+    x = full.pos[:, 0]
+    x_min, x_max = float(x.min()) - 1.0e-3, float(x.max()) + 1.0e-3
+    cuts = slab_cuts(slab_histogram(full.pos, x_min, x_max, bins), x_min, x_max, world_size)
+    mine = np.nonzero(slab_owners(full.pos, cuts) == rank)[0]
+    sc = scenes.Scene(f"{full.name}_slab{rank}of{world_size}", np.ascontiguousarray(full.pos[mine]),
+                      None if full.shape_type is None else np.ascontiguousarray(full.shape_type[mine]),
+                      None if full.half_extent is None else np.ascontiguousarray(full.half_extent[mine]),
+                      full.flags, full.solver_iterations, **full.cfg_overrides)
+    far = 1.0e30  # the outer faces of the first and the last slab: nobody lives beyond them
+    x_lo = -far if rank == 0 else float(cuts[rank])
+    x_hi = far if rank == world_size - 1 else float(cuts[rank + 1])
+    return sc, x_lo, x_hi, mine.astype(np.uint32), full.n
+
+
 def static_reach(half_extent, margin):
     """Upper bound of any fattened AABB edge: a rotated box is at most 2*|h| wide."""
     h = np.asarray(half_extent, np.float64).reshape(-1, 3)
@@ -173,8 +193,13 @@ class _BenchHalo:
         return self.last_cross_pairs
 
 
-def make_rank_scene(workload, rank, world_size, dist, local_rank, pinned_host=False):
-    sc, x_lo, x_hi, gids = rank_scene(workload, rank, world_size)
+def make_rank_scene(workload, rank, world_size, dist, local_rank, pinned_host=False, strong=False):
+    """strong: the workload's ONE scene cut into equal-count slabs (the broad-phase-only configuration C4 by default);
+    otherwise weak scaling: a workload-shaped slab per rank, side by side along x."""
+    if strong:
+        sc, x_lo, x_hi, gids, _ = strong_rank_scene(workload, rank, world_size)
+    else:
+        sc, x_lo, x_hi, gids = rank_scene(workload, rank, world_size)
     # records per slab face and step: the bodies that start within reach of it, with 1.5x headroom for what the pile does
     # later (a block is sent whole: capacity is bandwidth), never fewer than 4096
     reach = static_reach(sc.half_extent, sc.config().contact_margin)
@@ -182,7 +207,12 @@ def make_rank_scene(workload, rank, world_size, dist, local_rank, pinned_host=Fa
     near = max(int(np.count_nonzero(x < x_lo + reach)), int(np.count_nonzero(x > x_hi - reach)))
     cap = max(4096, near + near // 2)
     if sc.flags & scenes.FLAG_BROADPHASE_ONLY:
-        halo = HaloExchange(dist, rank, world_size, f"cuda:{local_rank}", cap, pinned_host=pinned_host)
+        if pinned_host:  # rehearsal of N ranks on one GPU: gloo over pinned host buffers around the pack / pairs kernels
+            halo = HaloExchange(dist, rank, world_size, f"cuda:{local_rank}", cap, pinned_host=True)
+        else:
+            # behind the C ABI (phys_halo_exchange: pack AABB records -> RCCL -> cross pairs, on the world's stream); the
+            # slabs are ordered by rank and far wider than the reach: one grouped ncclSend / ncclRecv pair per face
+            halo = GhostExchange(dist, rank, world_size, cap, transport="rccl", neighbours=True)
         return sc, _BenchHalo(halo, x_lo, x_hi, gids, before_update=False)
     # full step: neighbours' boundary bodies become ghosts of this rank (contacts across the cut planes)
     sc.cfg_overrides["max_ghosts"] = 2 * cap

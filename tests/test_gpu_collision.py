@@ -42,6 +42,33 @@ def test_broadphase_pairs_and_aabbs(n, extent):
         assert len(pw) > n // 4  # the soup really overlaps
 
 
+@pytest.mark.parametrize("name,n,box,he_hi", [
+    ("cube", 60000, (45.0, 45.0, 45.0), 1.2),      # isotropic soup: the table's bits split evenly
+    ("tower", 50000, (6.0, 300.0, 6.0), 1.2),      # 12 x 600 x 12: most of the bits go to y (grid_plan)
+    ("slab", 50000, (150.0, 3.0, 150.0), 1.2),     # flat: hardly any bits for y - an axis of 4 cells wraps constantly
+    ("dense", 40000, (10.0, 10.0, 10.0), 1.0),     # ~70 overlaps per body: regions beyond the LDS stage (global walk)
+])
+def test_broadphase_brick_kernel_against_the_oracle(name, n, box, he_hi):
+    """Above 32768 bodies the pair search is one workgroup per brick of 4 x 4 x 4 cells with the brick's half-shell region
+    staged in LDS (k_find_pairs_brick): the pair SET must equal the oracle's sort-and-sweep for every shape of scene -
+    whatever the split of the bucket table over the axes, with cells that wrap, and where a region holds more records
+    than the stage (those bricks walk global memory)."""
+    import physics_amd
+    rng = np.random.default_rng(len(name) + n)
+    pos = (rng.uniform(-1.0, 1.0, size=(n, 3)) * np.array(box)).astype(np.float32)
+    q = rng.normal(size=(n, 4)).astype(np.float32)
+    q /= np.linalg.norm(q, axis=1, keepdims=True).astype(np.float32)
+    st = rng.integers(0, 3, size=n).astype(np.uint32)
+    he = rng.uniform(0.3, he_hi, size=(n, 3)).astype(np.float32)
+    cfg = lambda: physics_amd.default_config(flags=physics_amd.FLAG_COLLISIONS, max_pairs=96 * n)
+    w, o = _worlds(cfg)
+    for x in (w, o):
+        x.set_bodies(pos, rot=q, shape_type=st, half_extent=he)
+    pw, po = w.broadphase(), o.broadphase_grid()
+    assert pw.shape == po.shape and np.array_equal(pw, po), (name, pw.shape, po.shape)
+    assert len(pw) > n // 2
+
+
 def test_broadphase_empty_and_none_shapes():
     import physics_amd
     cfg = physics_amd.default_config(flags=physics_amd.FLAG_COLLISIONS)

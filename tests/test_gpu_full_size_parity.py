@@ -68,10 +68,10 @@ def test_c5_256k_tower_three_steps_equal_the_oracle():
 
 
 def test_t1m_1m_cubes_three_steps_equal_the_oracle():
-    """The north_star scene: 1M cubes, state after 105 updates (>= 300k manifolds in the bottom third of the pile):
+    """The north_star scene: 1M cubes, state after 125 updates (>= 300k manifolds in the bottom third of the pile):
     DYNAMIC homes of the cluster solver, dealt out on the device."""
     from physics_amd import scenes
-    assert _three_steps_side_by_side(scenes.target_1m(), 105, 300_000) >= 300_000
+    assert _three_steps_side_by_side(scenes.target_1m(), 125, 300_000) >= 300_000
 
 
 def test_c3_100k_mixed_three_steps_equal_the_oracle():

@@ -123,3 +123,50 @@ def test_rank_scene_layout():
     assert a[0].pos[:, 0].max() < a[2] + 0.06 and b[0].pos[:, 0].min() > b[1] - 0.06
     from physics_amd import scenes
     assert np.array_equal(sharding.rank_scene("c2", 0, 1)[0].pos, scenes.c2().pos)
+
+
+# ---- strong scaling: ONE scene cut into equal-count slabs (BASELINE config 4) -----------------------------------------
+def _strong_scene():
+    from physics_amd import scenes
+    return scenes.c4(14, 6, 6)  # 504 bodies, spacing 2.2, jitter 0.3: dense AABB overlaps, across the cut planes too
+
+
+def _strong_worker(rank, world_size, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world_size)
+    try:
+        sc, x_lo, x_hi, gids, n_full = sharding.strong_rank_scene("c4", rank, world_size, scene=_strong_scene())
+        w = OracleHaloWorld(sc)
+        halo = sharding.HaloExchange(dist, rank, world_size, "cpu", cap=512)
+        halo.attach(w, x_lo, x_hi, gids, sc.half_extent, 0.02)
+        halo.exchange(w)
+        local = w.local_pairs_global()
+        cross = np.stack([gids[w.cross[:, 0]], w.cross[:, 1]], 1) if len(w.cross) else np.zeros((0, 2), np.uint32)
+        np.save(os.path.join(out_dir, f"pairs_{rank}.npy"), np.concatenate([local, cross]).astype(np.uint32))
+        np.save(os.path.join(out_dir, f"meta_{rank}.npy"), np.array([sc.n, len(cross), n_full, x_lo, x_hi]))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world_size", [2, 3])
+def test_strong_scaling_cut_of_one_scene(world_size, tmp_path):
+    """sharding.strong_rank_scene: histogram of body x -> prefix sums -> equal-count cut planes (phys_slab_*), every rank
+    keeps its slab of the ONE scene under the scene's own ids. Slabs are disjoint, cover the scene, hold n / ranks bodies
+    each (+- the bodies of one histogram bin), and the union of (local pairs, cross pairs) is the single-world pair set."""
+    from oracle import binding as ob
+    mp.spawn(_strong_worker, args=(world_size, _free_port(), str(tmp_path)), nprocs=world_size, join=True)
+    full = _strong_scene()
+    metas = [np.load(tmp_path / f"meta_{r}.npy") for r in range(world_size)]
+    assert sum(int(m[0]) for m in metas) == full.n and all(int(m[2]) == full.n for m in metas)
+    assert all(abs(int(m[0]) - full.n / world_size) <= 0.08 * full.n for m in metas), [m[0] for m in metas]
+    assert all(metas[r][4] == metas[r + 1][3] for r in range(world_size - 1))  # the slabs abut
+    got = np.concatenate([np.load(tmp_path / f"pairs_{r}.npy") for r in range(world_size)])
+    got = np.array(sorted(map(tuple, got.tolist())), np.uint32)
+    o = ob.OracleWorld(default_config(flags=FLAG_COLLISIONS), trig=ob.TRIG_DET)
+    full.populate(o)
+    want = o.broadphase()
+    assert len(np.unique(got, axis=0)) == len(got), "a pair was emitted twice"
+    assert np.array_equal(got, want)
+    assert sum(m[1] for m in metas) > 0, "no cross-rank pair in the test scene"
