@@ -244,19 +244,24 @@ def timed_period(rig, preroll, warmup):
     rig.advance(w, warmup)
     rig.fence(w)
     period = 64
-    slowest = 0.0
+    per_step = []
     t0 = time.perf_counter()
     for _ in range(period):
         t1 = time.perf_counter()
         rig.advance(w, 1)
         w.sync()
-        slowest = max(slowest, time.perf_counter() - t1)
+        per_step.append(time.perf_counter() - t1)
     torch.cuda.synchronize()
     if rig.dist is not None:
         rig.dist.barrier()
     elapsed = rig.max_over_ranks(time.perf_counter() - t0)
     w.close()
-    return period / elapsed, 1e3 * slowest
+    # a HITCH is a step far slower than the steps around it (a growing pile makes every later step slower: no hitch)
+    hitch = 0.0
+    for i, t in enumerate(per_step):
+        near = sorted(per_step[max(0, i - 4):i] + per_step[i + 1:i + 5])
+        hitch = max(hitch, t / near[len(near) // 2])
+    return period / elapsed, 1e3 * max(per_step), 1e3 * statistics.median(per_step), hitch, 1e3 * per_step[0], 1e3 * per_step[-1]
 
 
 def profile_window(rig, preroll, warmup, steps, workload_key):
@@ -426,8 +431,10 @@ def measure_workload(rig, args, preroll, reps, with_cpu):
         "scene_stats": st, "n_bodies": n_total, "preroll": preroll, "cross_pairs_rank": cross,
     }
     if (rig.scene.flags & 1) and not (rig.scene.flags & 8) and st["n_manifolds"] > 0:  # FLAG_COLLISIONS, not broad-phase-only
-        sps, slowest = timed_period(rig, preroll, args.warmup)
+        sps, slowest, med, hitch, first, last = timed_period(rig, preroll, args.warmup)
         rec["full_period"] = {"steps": 64, "steps_per_sec": round(sps, 2), "slowest_step_ms": round(slowest, 3),
+                              "median_step_ms": round(med, 3), "first_step_ms": round(first, 3), "last_step_ms": round(last, 3),
+                              "worst_step_over_median_of_its_8_neighbours": round(hitch, 3),
                               "note": "64 consecutive steps from the start of the timed window, synchronised after every step: "
                                       "contains exactly one rebuild of the persistent colour table (every 64th update; colours are "
                                       "never re-made: contact_solve.h) and, with dynamic clusters, eight deals of the homes; the scene "

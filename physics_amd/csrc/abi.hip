@@ -169,7 +169,7 @@ int32_t phys_destroy(phys_world* w) {
     if (w->stream) (void)hipStreamSynchronize(w->stream);
     DevBuf<float>* fb[] = {&w->pos, &w->rot, &w->vel, &w->force, &w->torque, &w->inv_inertia_diag,
                            &w->inv_inertia, &w->half_extent, &w->aabb, &w->cg_x, &w->cg_r, &w->cg_p, &w->cg_ap,
-                           &w->cg_rhs, &w->cg_c, &w->cg_scratch, &w->cg_jl, &w->man_geo, &w->row_n,
+                           &w->cg_rhs, &w->cg_c, &w->cg_scratch, &w->cg_jl, &w->geo, &w->man_geo, &w->row_n,
                            &w->row_pt, &w->row_tb, &w->row_acc, &w->row_all, &w->flow_vel, &w->sorted_box, &w->slot_box};
     for (auto* b : fb) b->free();
     DevBuf<uint32_t>* ub[] = {&w->shape, &w->global_id, &w->cg_status, &w->bucket_of, &w->bucket_count,
@@ -208,6 +208,7 @@ int32_t phys_set_bodies(phys_world* w, uint64_t n, const float* pos, const float
     PHYS_HIP_TRY(w->inv_inertia.resize(9 * nt)); PHYS_HIP_TRY(w->inv_inertia_diag.resize(4 * nt));
     PHYS_HIP_TRY(w->half_extent.resize(3 * nt)); PHYS_HIP_TRY(w->aabb.resize(6 * nt)); PHYS_HIP_TRY(w->shape.resize(nt));
     PHYS_HIP_TRY(w->global_id.resize(nt));
+    if ((w->cfg.flags & PHYS_FLAG_COLLISIONS) && !(w->cfg.flags & PHYS_FLAG_BROADPHASE_ONLY)) PHYS_HIP_TRY(w->geo.resize(16 * nt));
     w->n = nt;
     w->n_owned = n;
     w->max_ghosts = nt - n;

@@ -394,7 +394,38 @@ __global__ __launch_bounds__(kPairThreads) void k_find_pairs(const uint32_t* __r
 // comes first in the half-shell order; own-cell pairs by id order).
 constexpr int kRegX = 6, kRegY = 6, kRegZ = 5, kRegCells = kRegX * kRegY * kRegZ;  // 180
 constexpr int kBrickLanesPerBody = 4;
-constexpr int kBrickStagePerWave = 256;  // pairs staged per wave before a flush (2 KiB)
+constexpr int kBrickStagePerWave = 512;  // pairs staged per wave (4 KiB)
+
+// WHAT THE PAIR SEARCH WAITS FOR IS THE PAIR COUNTER. Same-address atomics serialise chip-wide at ~88 per microsecond, and
+// every flush of a stage is one: the one-lane-per-body kernel flushes once per wave (1M bodies: 15.6k flushes = 180 of
+// its 204 us), a first version of this kernel with one brick per workgroup flushed 80k times (814 us). So the workgroups
+// are PERSISTENT - a few per CU, each working through many bricks - and keep their hits in LDS across bricks; between two
+// bricks, once half the stage is full, the four waves' hits go out behind ONE atomic (C4: ~2.5k atomics for 1.3M pairs).
+// A wave whose own part fills up inside a brick (dense scenes) still flushes on its own.
+__device__ __forceinline__ void workgroup_flush(PairStage& st, uint32_t* s_cnt, uint32_t* s_base, uint32_t* __restrict__ pairs,
+                                                uint64_t max_pairs, StepCounters* __restrict__ ctr, bool force) {
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    if (lane == 0) s_cnt[wave] = st.count;
+    __syncthreads();
+    const uint32_t total = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+    const bool go = total != 0u && (force || total >= (uint32_t)(2 * kBrickStagePerWave));  // workgroup-uniform
+    if (go && threadIdx.x == 0) {
+        const uint32_t base = atomicAdd(&ctr->n_pairs, total);
+        if ((uint64_t)base + total > max_pairs) flag_overflow(ctr, 1u);
+        *s_base = base;
+    }
+    __syncthreads();
+    if (go) {
+        uint32_t off = *s_base;
+        for (uint32_t k = 0; k < wave; ++k) off += s_cnt[k];
+        for (uint32_t k = lane; k < st.count; k += 64) {
+            const uint64_t dst = (uint64_t)off + k;
+            if (dst < max_pairs) reinterpret_cast<uint2*>(pairs)[dst] = reinterpret_cast<const uint2*>(st.lds)[k];
+        }
+        st.count = 0;
+    }
+    __syncthreads();  // s_cnt / s_base are reused by the next flush
+}
 
 template <int CAP /* records staged per brick */>
 __global__ __launch_bounds__(kPairThreads) void k_find_pairs_brick(const uint32_t* __restrict__ bucket_start, uint32_t n_bricks,
@@ -406,119 +437,137 @@ __global__ __launch_bounds__(kPairThreads) void k_find_pairs_brick(const uint32_
     __shared__ uint32_t s_gstart[kRegCells];    // position of a region cell's first record in the sorted arrays
     __shared__ uint32_t s_off[kRegCells + 1];   // exclusive scan of the cells' record counts (position in s_rec)
     __shared__ float s_rec[CAP * 7];            // {lo xyz, hi xyz, id}: odd stride, distinct banks for neighbouring records
-    __shared__ uint32_t s_wsum[4];
-    // XCD-aware deal (a label, never relied on for correctness): workgroups with equal blockIdx % 8 share an L2
-    uint32_t brick = blockIdx.x;
-    if (n_bricks >= 8u && gridDim.x == n_bricks) brick = (blockIdx.x & 7u) * (n_bricks >> 3) + (blockIdx.x >> 3);
-    if (brick >= n_bricks) return;
-    const uint32_t own_begin = bucket_start[brick * 64u], own_end = bucket_start[brick * 64u + 64u];
-    if (own_begin == own_end) return;  // workgroup-uniform: an empty brick
+    __shared__ uint32_t s_wsum[4], s_cnt[4], s_base;
     PairStage st;
     st.lds = stage + (threadIdx.x >> 6) * kBrickStagePerWave * 2;
     st.count = 0;
-    const uint32_t bx = brick & ((1u << g.sx) - 1u), by = (brick >> g.sx) & ((1u << g.sy) - 1u), bz = brick >> (g.sx + g.sy);
-    const uint32_t ox = bx << 2, oy = by << 2, oz = bz << 2;
-    // 1. bucket ranges of the region's cells, scanned
-    {
-        uint32_t cnt = 0;
-        if (threadIdx.x < (uint32_t)kRegCells) {
-            const uint32_t r = threadIdx.x;
-            const uint32_t rx = r % kRegX, ry = (r / kRegX) % kRegY, rz = r / (kRegX * kRegY);
-            const uint32_t bk = grid_bucket_masked((ox + rx - 1u) & g.mx, (oy + ry - 1u) & g.my, (oz + rz) & g.mz, g);
-            const uint32_t b0 = bucket_start[bk], b1 = bucket_start[bk + 1];
-            s_gstart[r] = b0;
-            cnt = b1 - b0;
-        }
-        const uint32_t inc = wave_inclusive_scan(cnt);
-        if ((threadIdx.x & 63u) == 63u) s_wsum[threadIdx.x >> 6] = inc;
-        __syncthreads();
-        uint32_t base = 0;
-        for (uint32_t k = 0; k < (threadIdx.x >> 6); ++k) base += s_wsum[k];
-        if (threadIdx.x < (uint32_t)kRegCells) s_off[threadIdx.x] = base + inc - cnt;
-        if (threadIdx.x == (uint32_t)kRegCells - 1u) s_off[kRegCells] = base + inc;
-        __syncthreads();
-    }
-    const uint32_t total = s_off[kRegCells];
-    const bool staged = total <= (uint32_t)CAP;
-    // 2. the region's records into LDS
-    if (staged) {
-        for (uint32_t q = threadIdx.x; q < total; q += kPairThreads) {
-            uint32_t lo = 0, hi = kRegCells;  // the cell r with s_off[r] <= q < s_off[r + 1]
-            while (hi - lo > 1u) {
-                const uint32_t mid = (lo + hi) >> 1;
-                if (s_off[mid] <= q) lo = mid; else hi = mid;
-            }
-            const uint32_t t = s_gstart[lo] + (q - s_off[lo]);
-            const v3 blo = ld3(sorted_box, 2 * t), bhi = ld3(sorted_box, 2 * t + 1);
-            float* rec = s_rec + 7u * q;
-            rec[0] = blo.x; rec[1] = blo.y; rec[2] = blo.z; rec[3] = bhi.x; rec[4] = bhi.y; rec[5] = bhi.z;
-            rec[6] = __uint_as_float(sorted_ids[t]);
-        }
-        __syncthreads();
-    }
-    // 3. the brick's own bodies, four lanes each, against the 14 cells of their half shell
     const float inv_cell = grid_inv_cell(ctr);
-    const uint32_t n_own = own_end - own_begin;
     const uint32_t sub = threadIdx.x % kBrickLanesPerBody;
-    constexpr uint32_t kBodiesPerTrip = kPairThreads / kBrickLanesPerBody;
-    for (uint32_t base = 0; base < n_own; base += kBodiesPerTrip) {
-        const uint32_t jo = base + threadIdx.x / kBrickLanesPerBody;
-        const bool live = jo < n_own;
-        uint32_t i = 0;
-        aabb_t bi;
-        bi.lo = v3_make(0, 0, 0); bi.hi = v3_make(0, 0, 0);
-        uint32_t lx = 0, ly = 0, lz = 0;
-        if (live) {
-            const uint32_t sidx = own_begin + jo;
-            i = sorted_ids[sidx];
-            bi.lo = ld3(sorted_box, 2 * sidx);
-            bi.hi = ld3(sorted_box, 2 * sidx + 1);
-            // the brick's origin is a multiple of four cells on every axis: the low two bits are the place in the brick
-            lx = (uint32_t)cell_coord(0.5f * (bi.lo.x + bi.hi.x), inv_cell) & 3u;
-            ly = (uint32_t)cell_coord(0.5f * (bi.lo.y + bi.hi.y), inv_cell) & 3u;
-            lz = (uint32_t)cell_coord(0.5f * (bi.lo.z + bi.hi.z), inv_cell) & 3u;
-        }
-#pragma unroll
-        for (int k = 0; k < (14 + kBrickLanesPerBody - 1) / kBrickLanesPerBody; ++k) {
-            const int c = (int)sub + kBrickLanesPerBody * k;
-            int dx, dy, dz;  // half shell: own cell (c = 0) + the 13 cells with (dz, dy, dx) > (0, 0, 0) lexicographically
-            if (c == 0) { dx = 0; dy = 0; dz = 0; }
-            else if (c == 1) { dx = 1; dy = 0; dz = 0; }
-            else if (c < 5) { dx = c - 3; dy = 1; dz = 0; }
-            else { dx = (c - 5) % 3 - 1; dy = ((c - 5) / 3) % 3 - 1; dz = 1; }
-            uint32_t t = 0, t_end = 0;
-            if (live && c < 14) {
-                const uint32_t rid = ((lz + (uint32_t)dz) * kRegY + (ly + (uint32_t)(dy + 1))) * kRegX + (lx + (uint32_t)(dx + 1));
-                const uint32_t o0 = s_off[rid], o1 = s_off[rid + 1];
-                t = staged ? o0 : s_gstart[rid];
-                t_end = t + (o1 - o0);
-            }
-            const bool own_cell = c == 0;
-            while (__any(t < t_end)) {
-                bool hit = false;
-                uint32_t j = 0;
-                if (t < t_end) {
-                    aabb_t bj;
-                    if (staged) {
-                        const float* rec = s_rec + 7u * t;
-                        bj.lo = v3_make(rec[0], rec[1], rec[2]);
-                        bj.hi = v3_make(rec[3], rec[4], rec[5]);
-                        j = __float_as_uint(rec[6]);
-                    } else {
-                        j = sorted_ids[t];
-                        bj.lo = ld3(sorted_box, 2 * t);
-                        bj.hi = ld3(sorted_box, 2 * t + 1);
-                    }
-                    // own cell: each unordered pair once by id order. Other cells: a bucket can alias a far cell
-                    // (wrap-around); such a candidate fails the overlap test, and the 14 buckets are distinct.
-                    hit = aabb_overlap(bi, bj) && (!own_cell || i < j);
-                    ++t;
-                }
-                stage_push<kBrickStagePerWave>(st, hit, i < j ? i : j, i < j ? j : i, pairs, max_pairs, ctr);
-            }
-        }
+    // XCD-aware deal (a label, never relied on for correctness): workgroups with equal blockIdx % 8 share an L2 and take
+    // ONE contiguous eighth of the table between them, brick by brick in turn (neighbouring bricks are in flight together
+    // on one L2, and the empty bricks of a scene that fills part of its table are spread over all workgroups)
+    uint32_t first = blockIdx.x, last = n_bricks, step = gridDim.x;
+    if (gridDim.x >= 8u && n_bricks >= 8u) {
+        const uint32_t label = blockIdx.x & 7u, per = n_bricks >> 3;  // n_bricks is a power of two
+        step = (gridDim.x - label + 7u) >> 3;
+        first = label * per + (blockIdx.x >> 3);
+        last = (label + 1u) * per;
     }
-    stage_flush(st, pairs, max_pairs, ctr);
+    for (uint32_t brick = first; brick < last; brick += step) {
+        const uint32_t own_begin = bucket_start[brick * 64u], own_end = bucket_start[brick * 64u + 64u];
+        if (own_begin == own_end) continue;  // workgroup-uniform: an empty brick
+        const uint32_t bx = brick & ((1u << g.sx) - 1u), by = (brick >> g.sx) & ((1u << g.sy) - 1u), bz = brick >> (g.sx + g.sy);
+        const uint32_t ox = bx << 2, oy = by << 2, oz = bz << 2;
+        // the brick's own bodies: asked for now, needed after the staging (two round trips later)
+        constexpr uint32_t kBodiesPerTrip = kPairThreads / kBrickLanesPerBody;
+        const uint32_t n_own = own_end - own_begin;
+        uint32_t i0 = 0;
+        aabb_t b0;
+        b0.lo = v3_make(0, 0, 0); b0.hi = v3_make(0, 0, 0);
+        if (threadIdx.x / kBrickLanesPerBody < n_own) {
+            const uint32_t sidx = own_begin + threadIdx.x / kBrickLanesPerBody;
+            i0 = sorted_ids[sidx];
+            b0.lo = ld3(sorted_box, 2 * sidx);
+            b0.hi = ld3(sorted_box, 2 * sidx + 1);
+        }
+        // 1. bucket ranges of the region's cells, scanned
+        {
+            uint32_t cnt = 0;
+            if (threadIdx.x < (uint32_t)kRegCells) {
+                const uint32_t r = threadIdx.x;
+                const uint32_t rx = r % kRegX, ry = (r / kRegX) % kRegY, rz = r / (kRegX * kRegY);
+                const uint32_t bk = grid_bucket_masked((ox + rx - 1u) & g.mx, (oy + ry - 1u) & g.my, (oz + rz) & g.mz, g);
+                const uint32_t c0 = bucket_start[bk], c1 = bucket_start[bk + 1];
+                s_gstart[r] = c0;
+                cnt = c1 - c0;
+            }
+            const uint32_t inc = wave_inclusive_scan(cnt);
+            if ((threadIdx.x & 63u) == 63u) s_wsum[threadIdx.x >> 6] = inc;
+            __syncthreads();
+            uint32_t base = 0;
+            for (uint32_t k = 0; k < (threadIdx.x >> 6); ++k) base += s_wsum[k];
+            if (threadIdx.x < (uint32_t)kRegCells) s_off[threadIdx.x] = base + inc - cnt;
+            if (threadIdx.x == (uint32_t)kRegCells - 1u) s_off[kRegCells] = base + inc;
+            __syncthreads();
+        }
+        const uint32_t total = s_off[kRegCells];
+        const bool staged = total <= (uint32_t)CAP;
+        // 2. the region's records into LDS
+        if (staged) {
+            for (uint32_t q = threadIdx.x; q < total; q += kPairThreads) {
+                uint32_t lo = 0, hi = kRegCells;  // the cell r with s_off[r] <= q < s_off[r + 1]
+                while (hi - lo > 1u) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (s_off[mid] <= q) lo = mid; else hi = mid;
+                }
+                const uint32_t t = s_gstart[lo] + (q - s_off[lo]);
+                const v3 blo = ld3(sorted_box, 2 * t), bhi = ld3(sorted_box, 2 * t + 1);
+                float* rec = s_rec + 7u * q;
+                rec[0] = blo.x; rec[1] = blo.y; rec[2] = blo.z; rec[3] = bhi.x; rec[4] = bhi.y; rec[5] = bhi.z;
+                rec[6] = __uint_as_float(sorted_ids[t]);
+            }
+            __syncthreads();
+        }
+        // 3. the brick's own bodies, four lanes each, against the 14 cells of their half shell
+        for (uint32_t base = 0; base < n_own; base += kBodiesPerTrip) {
+            const uint32_t jo = base + threadIdx.x / kBrickLanesPerBody;
+            const bool live = jo < n_own;
+            uint32_t i = i0;
+            aabb_t bi = b0;
+            if (base != 0u && live) {
+                const uint32_t sidx = own_begin + jo;
+                i = sorted_ids[sidx];
+                bi.lo = ld3(sorted_box, 2 * sidx);
+                bi.hi = ld3(sorted_box, 2 * sidx + 1);
+            }
+            // the brick's origin is a multiple of four cells on every axis: the low two bits are the place in the brick
+            const uint32_t lx = (uint32_t)cell_coord(0.5f * (bi.lo.x + bi.hi.x), inv_cell) & 3u;
+            const uint32_t ly = (uint32_t)cell_coord(0.5f * (bi.lo.y + bi.hi.y), inv_cell) & 3u;
+            const uint32_t lz = (uint32_t)cell_coord(0.5f * (bi.lo.z + bi.hi.z), inv_cell) & 3u;
+#pragma unroll
+            for (int k = 0; k < (14 + kBrickLanesPerBody - 1) / kBrickLanesPerBody; ++k) {
+                const int c = (int)sub + kBrickLanesPerBody * k;
+                int dx, dy, dz;  // half shell: own cell (c = 0) + the 13 cells with (dz, dy, dx) > (0, 0, 0) lexicographically
+                if (c == 0) { dx = 0; dy = 0; dz = 0; }
+                else if (c == 1) { dx = 1; dy = 0; dz = 0; }
+                else if (c < 5) { dx = c - 3; dy = 1; dz = 0; }
+                else { dx = (c - 5) % 3 - 1; dy = ((c - 5) / 3) % 3 - 1; dz = 1; }
+                uint32_t t = 0, t_end = 0;
+                if (live && c < 14) {
+                    const uint32_t rid = ((lz + (uint32_t)dz) * kRegY + (ly + (uint32_t)(dy + 1))) * kRegX + (lx + (uint32_t)(dx + 1));
+                    const uint32_t o0 = s_off[rid], o1 = s_off[rid + 1];
+                    t = staged ? o0 : s_gstart[rid];
+                    t_end = t + (o1 - o0);
+                }
+                const bool own_cell = c == 0;
+                while (__any(t < t_end)) {
+                    bool hit = false;
+                    uint32_t j = 0;
+                    if (t < t_end) {
+                        aabb_t bj;
+                        if (staged) {
+                            const float* rec = s_rec + 7u * t;
+                            bj.lo = v3_make(rec[0], rec[1], rec[2]);
+                            bj.hi = v3_make(rec[3], rec[4], rec[5]);
+                            j = __float_as_uint(rec[6]);
+                        } else {
+                            j = sorted_ids[t];
+                            bj.lo = ld3(sorted_box, 2 * t);
+                            bj.hi = ld3(sorted_box, 2 * t + 1);
+                        }
+                        // own cell: each unordered pair once by id order. Other cells: a bucket can alias a far cell
+                        // (wrap-around); such a candidate fails the overlap test, and the 14 buckets are distinct.
+                        hit = aabb_overlap(bi, bj) && (!own_cell || i < j);
+                        ++t;
+                    }
+                    stage_push<kBrickStagePerWave>(st, hit, i < j ? i : j, i < j ? j : i, pairs, max_pairs, ctr);
+                }
+            }
+        }
+        // the region tables and records are rewritten by the next brick: everybody is done with them behind the flush's barriers
+        workgroup_flush(st, s_cnt, &s_base, pairs, max_pairs, ctr, /*force=*/false);
+    }
+    workgroup_flush(st, s_cnt, &s_base, pairs, max_pairs, ctr, /*force=*/true);
 }
 
 // ---- slot grid (small scenes) ------------------------------------------------------------------------
@@ -838,15 +887,19 @@ void launch_broadphase(phys_world* w) {
     static const bool body_kernel = getenv("PHYS_DEBUG_PAIR_KERNEL") != nullptr && getenv("PHYS_DEBUG_PAIR_KERNEL")[0] == 'b';
     if (!body_kernel && !pair_lanes_env) {
         const uint32_t n_bricks = T >> 6;
-        // records staged per brick: 640 (28 KiB of LDS per workgroup, five per CU) covers lattices and falling piles; scenes
+        // records staged per brick: 640 (36 KiB of LDS per workgroup, four per CU) covers lattices and falling piles; scenes
         // with many pairs per body (resting piles of rotated boxes: big cells, several bodies each) take the larger stage
         const bool dense = w->hint.valid && (uint64_t)w->hint.n_pairs > 5ull * w->n;
+        // persistent workgroups, as many as are resident at once (the LDS decides), never more than there are bricks
+        const uint32_t per_cu = dense ? 2u : 4u;
+        uint32_t wgs = 256u * per_cu;
+        while (wgs > n_bricks) wgs >>= 1;
         PHYS_PROF(w, PHYS_STAGE_PAIRS);
         if (dense)
-            hipLaunchKernelGGL((k_find_pairs_brick<2048>), dim3(n_bricks), dim3(kPairThreads), 0, s, w->bucket_start.p, n_bricks, axis_mask,
+            hipLaunchKernelGGL((k_find_pairs_brick<2048>), dim3(wgs), dim3(kPairThreads), 0, s, w->bucket_start.p, n_bricks, axis_mask,
                                w->sorted_ids.p, w->sorted_box.p, w->pairs.p, w->max_pairs, w->counters.p);
         else
-            hipLaunchKernelGGL((k_find_pairs_brick<640>), dim3(n_bricks), dim3(kPairThreads), 0, s, w->bucket_start.p, n_bricks, axis_mask,
+            hipLaunchKernelGGL((k_find_pairs_brick<640>), dim3(wgs), dim3(kPairThreads), 0, s, w->bucket_start.p, n_bricks, axis_mask,
                                w->sorted_ids.p, w->sorted_box.p, w->pairs.p, w->max_pairs, w->counters.p);
         return;
     }

@@ -159,9 +159,12 @@ bool cluster_plan_dynamic(phys_world* w) {
     // bodies); the plan is only made when they are dealt out again
     if (w->cluster_homes_valid && w->cluster_age < kClusterDynamicPeriod) return true;
     w->cluster_homes_valid = false;
-    // the count of the last deal; before the first one: no more bodies than twice the manifolds can be active
+    // the count of the last deal; before the first one: a pile has about as many bodies in contact as it has manifolds
+    // (between half as many and twice as many; a world seeded with a mid-fall state - 1M cubes, 360k manifolds, 250k
+    // active bodies - never got a first deal with the upper bound). Too low a guess leaves some bodies without a home for
+    // one period (slower, never wrong), and the deal itself then counts them.
     uint64_t active = w->hint.n_active;
-    if (active == 0) active = std::min<uint64_t>(w->n_owned, 2ull * w->hint.n_manifolds);
+    if (active == 0) active = std::min<uint64_t>(w->n_owned, (uint64_t)w->hint.n_manifolds);
     if (active == 0) return false;
     static const int spare_div = getenv("PHYS_DEBUG_CLUSTER_SPARE") ? atoi(getenv("PHYS_DEBUG_CLUSTER_SPARE")) : 8;
     static const char* per_cu_env = getenv("PHYS_DEBUG_CLUSTERS_PER_CU");

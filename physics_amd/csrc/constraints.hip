@@ -42,7 +42,13 @@ constexpr int kCgThreads = 1024;
 // at which CG stops); what can be taken out of them is everything else: the products are made by the whole workgroup,
 // kDotChunk at a time, into LDS (rounded once, as `acc += a * b` rounds them without contraction), and a chain then reads
 // eight of them per trip from LDS instead of waiting for two global loads per addition (24k rows: 3072 links per chain).
-constexpr uint32_t kDotChunk = 8192;  // products staged per trip (32 KiB of LDS)
+// The stage is CHAIN-major: chain c's products sit side by side (element 8k + c of the chunk at prod[c * kDotStride + k]),
+// so a chain reads sixteen links with four ds_read_b128 and adds them while the next sixteen are on their way; the
+// stride is 4 words off a multiple of the 32 banks, so the eight chains' reads fall on disjoint banks. (Element-major,
+// one ds_read_b32 per link: 62 cycles per link, 243 us per CG iteration at 24k rows; this layout: see DESIGN.md.)
+constexpr uint32_t kDotChunk = 8192;                 // products staged per trip
+constexpr uint32_t kDotStride = kDotChunk / 8 + 4;   // words between two chains' runs (1028)
+constexpr uint32_t kDotLdsWords = 8 * kDotStride;    // 32.1 KiB
 __device__ __forceinline__ float dyn_dot8(const float* __restrict__ a, const float* __restrict__ b, uint32_t n,
                                           float* __restrict__ lds8, float* __restrict__ prod) {
     const uint32_t lane = threadIdx.x;
@@ -50,16 +56,19 @@ __device__ __forceinline__ float dyn_dot8(const float* __restrict__ a, const flo
     float acc = 0.0f;
     for (uint32_t base = 0; base < full; base += kDotChunk) {
         const uint32_t m = full - base < kDotChunk ? full - base : kDotChunk;  // a multiple of 8
-        for (uint32_t i = threadIdx.x; i < m; i += kCgThreads) prod[i] = a[base + i] * b[base + i];
+        for (uint32_t i = threadIdx.x; i < m; i += kCgThreads) prod[(i & 7u) * kDotStride + (i >> 3)] = a[base + i] * b[base + i];
         __syncthreads();
         if (lane < 8) {
-            uint32_t i = lane;
-            for (; i + 56 < m; i += 64) {  // eight links per trip: the LDS reads of a trip are independent of its additions
-                const float p0 = prod[i], p1 = prod[i + 8], p2 = prod[i + 16], p3 = prod[i + 24], p4 = prod[i + 32],
-                            p5 = prod[i + 40], p6 = prod[i + 48], p7 = prod[i + 56];
-                acc += p0; acc += p1; acc += p2; acc += p3; acc += p4; acc += p5; acc += p6; acc += p7;
+            const float* run = prod + lane * kDotStride;  // this chain's m / 8 links, in order
+            const uint32_t links = m >> 3;
+            uint32_t k = 0;
+            for (; k + 16 <= links; k += 16) {
+                const float4 q0 = *reinterpret_cast<const float4*>(run + k), q1 = *reinterpret_cast<const float4*>(run + k + 4),
+                             q2 = *reinterpret_cast<const float4*>(run + k + 8), q3 = *reinterpret_cast<const float4*>(run + k + 12);
+                acc += q0.x; acc += q0.y; acc += q0.z; acc += q0.w; acc += q1.x; acc += q1.y; acc += q1.z; acc += q1.w;
+                acc += q2.x; acc += q2.y; acc += q2.z; acc += q2.w; acc += q3.x; acc += q3.y; acc += q3.z; acc += q3.w;
             }
-            for (; i < m; i += 8) acc += prod[i];
+            for (; k < links; ++k) acc += run[k];
         }
         __syncthreads();
     }
@@ -135,7 +144,7 @@ __global__ __launch_bounds__(kCgThreads) void k_constraint_solve(
     uint32_t* __restrict__ status /* [0] converged, [1] iterations, [2] previous_solution.is_some() */,
     float* __restrict__ jl /* 6: J^T lambda of entity 0, added to its accumulators by the step kernel when status[0] */) {
     __shared__ float lds8[8];
-    __shared__ float prod[kDotChunk];
+    __shared__ __attribute__((aligned(16))) float prod[kDotLdsWords];
     __shared__ float lds16[kCgThreads / 64];
     __shared__ int s_done;
     const uint32_t n = 3 * cp.n_constraints;

@@ -122,7 +122,8 @@ __global__ __launch_bounds__(256) void k_step_velocity_aabb(StepParams sp, const
                                                             const float* __restrict__ half_extent, float margin,
                                                             float* __restrict__ aabb, StepCounters* __restrict__ ctr,
                                                             uint4* __restrict__ zero_base, uint32_t zero_count,
-                                                            const float* __restrict__ jl, const uint32_t* __restrict__ cg_status) {
+                                                            const float* __restrict__ jl, const uint32_t* __restrict__ cg_status,
+                                                            float* __restrict__ geo /* 16 floats per body, or null */) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     // first kernel of the step: it also zeroes the per-step state of the stages behind it (bucket counts,
     // colouring state, counters up to max_extent_bits) instead of a memset launch in front of it
@@ -144,9 +145,16 @@ __global__ __launch_bounds__(256) void k_step_velocity_aabb(StepParams sp, const
         const float4 qq = reinterpret_cast<const float4*>(rot)[i];
         quat q; q.i = qq.x; q.j = qq.y; q.k = qq.z; q.w = qq.w;
         const uint32_t type = shape[i];
-        const aabb_t b = body_aabb(x, q, ld3(half_extent, i), type, margin);
+        const v3 he = ld3(half_extent, i);
+        const aabb_t b = body_aabb(x, q, he, type, margin);
         st3(aabb, 2 * i, b.lo);
         st3(aabb, 2 * i + 1, b.hi);
+        if (geo) {  // the narrow phase's view of this body: one line (world.hpp)
+            float4* g = reinterpret_cast<float4*>(geo) + 4 * (size_t)i;
+            g[0] = make_float4(x.x, x.y, x.z, __uint_as_float(type));
+            g[1] = qq;
+            g[2] = make_float4(he.x, he.y, he.z, b.lo.y);
+        }
         if (type != PHYS_SPEC_SHAPE_NONE)
             ext = det_maxf(b.hi.x - b.lo.x, det_maxf(b.hi.y - b.lo.y, b.hi.z - b.lo.z));
     }
@@ -302,7 +310,7 @@ void launch_step_velocity_aabb(phys_world* w, float dt, bool gravity, bool zero_
 #define LAUNCH(F, G, D)                                                                                            \
     hipLaunchKernelGGL((k_step_velocity_aabb<F, G, D>), g, b, 0, w->stream, sp, w->pos.p, w->rot.p, w->vel.p,      \
                        w->force.p, w->torque.p, D ? w->inv_inertia_diag.p : w->inv_inertia.p, w->shape.p,                \
-                       w->half_extent.p, margin, w->aabb.p, w->counters.p, zero_base, zero_count, jl, cg_status)
+                       w->half_extent.p, margin, w->aabb.p, w->counters.p, zero_base, zero_count, jl, cg_status, w->geo.p)
     const float* jl = constraints ? w->cg_jl.p : nullptr;
     const uint32_t* cg_status = constraints ? w->cg_status.p : nullptr;
     const int sel = (w->forces_dirty ? 4 : 0) | (gravity ? 2 : 0) | (diag ? 1 : 0);

@@ -21,11 +21,13 @@ namespace phys {
 constexpr uint32_t kUncolored = 0xFFFFFFFFu;
 
 
-__device__ __forceinline__ geom_t load_geom(uint32_t i, const float* __restrict__ pos, const float* __restrict__ rot,
-                                            const float* __restrict__ half_extent, const uint32_t* __restrict__ shape) {
-    const float4 qq = reinterpret_cast<const float4*>(rot)[i];
+// one body as the narrow phase sees it: three 16-byte loads from ONE 64-byte line (world.hpp `geo`, written by
+// k_step_velocity_aabb of this update from the same pose the AABBs were made of)
+__device__ __forceinline__ geom_t load_geom(uint32_t i, const float* __restrict__ geo) {
+    const float4* g = reinterpret_cast<const float4*>(geo) + 4 * (size_t)i;
+    const float4 g0 = g[0], qq = g[1], g2 = g[2];
     quat q; q.i = qq.x; q.j = qq.y; q.k = qq.z; q.w = qq.w;
-    return geom_make(ld3(pos, i), q, ld3(half_extent, i), shape[i]);
+    return geom_make(v3_make(g0.x, g0.y, g0.z), q, v3_make(g2.x, g2.y, g2.z), __float_as_uint(g0.w));
 }
 
 // kNpThreads: 128 for small scenes (latency-bound: more workgroups in flight, the LDS slice of the clipper
@@ -34,8 +36,7 @@ template <int kNpThreads>
 __global__ __launch_bounds__(kNpThreads) void k_narrowphase(
     uint32_t n_ground /* bodies tested against the plane (0 = no ground) */, uint32_t n_owned /* bodies at or beyond this
     index are ghosts of a sharded world: a pair of two ghosts belongs to other ranks */, const uint32_t* __restrict__ pairs,
-    uint64_t max_pairs, const float* __restrict__ pos, const float* __restrict__ rot,
-    const float* __restrict__ half_extent, const uint32_t* __restrict__ shape, const float* __restrict__ aabb,
+    uint64_t max_pairs, const float* __restrict__ geo /* 16 floats per body: {pos, shape} {rot} {half extent, AABB lo.y} */,
     float margin, float ground, uint64_t max_manifolds, uint32_t* __restrict__ man_a, uint32_t* __restrict__ man_b,
     uint32_t* __restrict__ man_color, float* __restrict__ man_geo /* 32 floats per manifold */,
     uint64_t* __restrict__ man_prio, unsigned long long* __restrict__ used,
@@ -59,6 +60,7 @@ __global__ __launch_bounds__(kNpThreads) void k_narrowphase(
     const uint32_t total = n_ground + n_pairs;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t trip = 0;
+    uint32_t acc_pts = 0, acc_ground = 0, acc_unc = 0;  // thread 0: statistics of this workgroup's trips, added once at the end
     for (uint32_t base = blockIdx.x * kNpThreads; base < total; base += gridDim.x * kNpThreads, ++trip) {
         const uint32_t idx = base + threadIdx.x;
         uint32_t* wcount = wtot[trip & 1u][0];
@@ -76,10 +78,11 @@ __global__ __launch_bounds__(kNpThreads) void k_narrowphase(
             // the fattened AABB of this step (k_step_velocity_aabb; lo.y = lowest corner - margin) rules most bodies out
             // without their orientation being read or a corner being made: a million-cube drop has 1 % of its bodies on
             // the plane. Conservative: a body is kept unless its AABB clears ground + margin by more than rounding.
-            const float lo_y = aabb[6 * (size_t)a + 1];
-            if (lo_y <= (ground + margin) + 1.0e-3f * (1.0f + det_absf(lo_y)) && shape[a] != PHYS_SPEC_SHAPE_NONE) {
-                const geom_t ga = load_geom(a, pos, rot, half_extent, shape);
-                collide_ground(&ga, ground, margin, &m, ws);
+            const float4 g2 = reinterpret_cast<const float4*>(geo)[4 * (size_t)a + 2];
+            const float lo_y = g2.w;
+            if (lo_y <= (ground + margin) + 1.0e-3f * (1.0f + det_absf(lo_y))) {
+                const geom_t ga = load_geom(a, geo);
+                if (ga.type != PHYS_SPEC_SHAPE_NONE) collide_ground(&ga, ground, margin, &m, ws);
             }
         } else if (idx < total) {
             const uint2 pr = reinterpret_cast<const uint2*>(pairs)[idx - n_ground];
@@ -93,8 +96,8 @@ __global__ __launch_bounds__(kNpThreads) void k_narrowphase(
                     early = cache[early_h];
                     have_early = true;
                 }
-                const geom_t ga = load_geom(a, pos, rot, half_extent, shape);
-                const geom_t gb = load_geom(b, pos, rot, half_extent, shape);
+                const geom_t ga = load_geom(a, geo);
+                const geom_t gb = load_geom(b, geo);
                 collide_pair(&ga, &gb, margin, &m, ws);
             }
         }
@@ -166,15 +169,17 @@ __global__ __launch_bounds__(kNpThreads) void k_narrowphase(
             uint32_t t = 0, tp = 0, tg = 0, tu = 0;
             for (int k = 0; k < kNpThreads / 64; ++k) { t += wcount[k]; tp += wpts[k]; tg += wground[k]; tu += wunc[k]; }
             uint32_t bb = 0, ub = 0;
-            if (t) bb = atomicAdd(&ctr->n_manifolds, t);
-            if (tu) ub = atomicAdd(&ctr->unc_count[0], tu);  // this workgroup's stretch of the round-0 list
             if (t) {
+                // ONE reservation for both lists: manifold slots (low word) and this workgroup's stretch of the round-0 list
+                // of uncoloured manifolds (high word); see StepCounters
+                const unsigned long long got = atomicAdd(reinterpret_cast<unsigned long long*>(&ctr->n_manifolds),
+                                                         ((unsigned long long)tu << 32) | t);
+                bb = (uint32_t)got;
+                ub = (uint32_t)(got >> 32);
                 const uint64_t room = (uint64_t)bb < max_manifolds ? max_manifolds - bb : 0;
                 const uint32_t stored = (uint64_t)t <= room ? t : (uint32_t)room;
                 if (stored != t) flag_overflow(ctr, 2u);
-                atomicAdd(&ctr->n_contacts, tp);
-                if (tg) atomicAdd(&ctr->n_ground_manifolds, tg);
-                if (tu) atomicAdd(&ctr->n_uncolored, tu);
+                acc_pts += tp; acc_ground += tg; acc_unc += tu;
             }
             block_base = bb;
             unc_base = ub;
@@ -214,6 +219,11 @@ __global__ __launch_bounds__(kNpThreads) void k_narrowphase(
         }
         // (block_base / unc_base are rewritten behind the next trip's first barrier, which every wave reaches only after it
         // has placed this trip's manifolds; the per-wave totals alternate between two sets)
+    }
+    if (threadIdx.x == 0) {
+        if (acc_pts) atomicAdd(&ctr->n_contacts, acc_pts);
+        if (acc_ground) atomicAdd(&ctr->n_ground_manifolds, acc_ground);
+        if (acc_unc) atomicAdd(&ctr->n_uncolored, acc_unc);
     }
 }
 
@@ -721,7 +731,7 @@ void launch_narrowphase(phys_world* w) {
         uint64_t blocks = (work + T - 1) / T;                                                                          \
         if (blocks > 256 * 16) blocks = 256 * 16;                                                                      \
         hipLaunchKernelGGL((k_narrowphase<T>), dim3((unsigned)blocks), dim3(T), 0, w->stream, n_ground, n_owned, w->pairs.p, \
-                           w->max_pairs, w->pos.p, w->rot.p, w->half_extent.p, w->shape.p, w->aabb.p, w->cfg.contact_margin, \
+                           w->max_pairs, w->geo.p, w->cfg.contact_margin, \
                            w->cfg.ground_height, w->max_manifolds, w->man_a.p, w->man_b.p,                             \
                            w->man_color.p, w->man_geo.p, w->man_prio.p, w->color_state.p,                              \
                            w->color_state.p + n, reinterpret_cast<ulonglong2*>(w->ctab.p), cache_mask, stamp,          \

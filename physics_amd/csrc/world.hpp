@@ -61,8 +61,12 @@ struct DevBuf {
 
 // device-side counters of the collision pipeline (one 256-B block, zeroed per step by one memset)
 struct StepCounters {
-    uint32_t n_pairs;        // candidate pairs written
+    // the first two words are reserved TOGETHER by the narrow phase: one 64-bit atomic per workgroup trip adds the trip's
+    // manifolds to the low word and its uncoloured manifolds to the high one (same-address atomics serialise chip-wide;
+    // two of them per trip was two places in that queue)
     uint32_t n_manifolds;    // manifolds written (body-body + ground)
+    uint32_t unc_count[3];   // colouring rounds: length of the list of uncoloured manifolds read / written / cleared (rotating)
+    uint32_t n_pairs;        // candidate pairs written
     uint32_t n_contacts;     // contact points
     uint32_t n_uncolored;    // manifolds still uncoloured (colouring loop)
     uint32_t n_colors;       // colours in use
@@ -77,7 +81,6 @@ struct StepCounters {
     uint32_t cluster_arrived[2][8];  // k_solve_cluster, per attempt: workgroups that have begun (eight counters: same-address
                                      // atomics serialise chip-wide) ...
     uint32_t cluster_state[2];       // ... and the launch's one decision: 0 undecided, 1 go (all are resident), 2 called off
-    uint32_t unc_count[3];   // colouring rounds: length of the list of uncoloured manifolds read / written / cleared (rotating)
     uint32_t color_count[kMaxColors];  // manifolds per colour
     uint32_t color_start[kMaxColors + 1];
     // LAST member: survives the per-step reset (only the bytes before it are zeroed), so a wave issues the
@@ -94,6 +97,8 @@ struct StepCounters {
     uint32_t n_halo_low; // neighbour exchange: records of the LOW-face block (n_halo then counts the high-face block; the stats add them)
     uint32_t debug[8];  // what a kernel that refused a corrupt row saw (overflow bit 5); never read by device code
 };
+static_assert(offsetof(StepCounters, n_manifolds) % 8 == 0 && offsetof(StepCounters, unc_count) == offsetof(StepCounters, n_manifolds) + 4,
+              "n_manifolds | unc_count[0] are one aligned 64-bit word");
 constexpr size_t kCountersStepResetBytes = offsetof(StepCounters, max_extent_bits);
 constexpr size_t kCountersExtentResetBytes = offsetof(StepCounters, sticky_overflow);
 
@@ -192,6 +197,10 @@ struct phys_world {
     phys::DevBuf<float> pos, rot, vel /* 8n: v.xyz inv_mass w.xyz mass */, force, torque, inv_inertia, inv_inertia_diag /* 4n, valid when all_diag_inertia */, half_extent, aabb;
     phys::DevBuf<uint32_t> shape;
     phys::DevBuf<uint32_t> global_id;
+    // what the narrow phase needs of a body, in ONE 64-byte line: {pos.xyz, shape} {rot ijkw} {half extent xyz, lowest y of
+    // the fattened AABB}; written once per update by k_step_velocity_aabb (which has it all in registers), gathered twice
+    // per candidate pair - instead of four 4-to-16-byte gathers per body out of four arrays (C5: 3M pairs per update)
+    phys::DevBuf<float> geo;  // 16 floats per body (48 bytes used)
 
     // constraints (A3-A7)
     std::vector<phys::Constraint> constraints;
