@@ -67,6 +67,8 @@ void poll_snapshots(phys_world* w) {
         w->hint.valid = true;
         w->hint.n_manifolds = c.n_manifolds;
         w->hint.n_pairs = c.n_pairs;
+        if (c.max_region) w->hint.max_region = c.max_region;
+        w->hint.n_used_buckets = c.n_used_buckets;
         w->hint.n_colors = c.n_colors;
         if (c.n_active) w->hint.n_active = c.n_active;  // counted only in the updates that deal out the dynamic homes
         // colouring rounds: a full re-colouring and an incremental update need very different counts, and the
@@ -379,6 +381,8 @@ static int32_t enqueue_update(phys_world* w, float dt) {
             launch_narrowphase(w);
             launch_coloring(w);
             launch_solver(w, dt);
+        } else {
+            snapshot_counters_async(w);  // launch-size hints of later updates (the colouring stage takes it otherwise)
         }
         launch_step_position(w, dt);
     }

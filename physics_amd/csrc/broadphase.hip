@@ -35,20 +35,36 @@ __device__ __forceinline__ float grid_inv_cell(const StepCounters* ctr) {
 
 __global__ __launch_bounds__(256) void k_cell_assign(uint32_t n, const float* __restrict__ aabb,
                                                      const uint32_t* __restrict__ shape,
-                                                     const StepCounters* __restrict__ ctr, GridShape axis_mask,
+                                                     StepCounters* __restrict__ ctr, GridShape axis_mask,
                                                      uint32_t* __restrict__ bucket_of, uint32_t* __restrict__ rank,
                                                      uint32_t* __restrict__ bucket_count) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    if (shape[i] == PHYS_SPEC_SHAPE_NONE) { bucket_of[i] = kInvalid; return; }
-    const float inv_cell = grid_inv_cell(ctr);
-    const v3 lo = ld3(aabb, 2 * i), hi = ld3(aabb, 2 * i + 1);
-    const int cx = cell_coord(0.5f * (lo.x + hi.x), inv_cell);
-    const int cy = cell_coord(0.5f * (lo.y + hi.y), inv_cell);
-    const int cz = cell_coord(0.5f * (lo.z + hi.z), inv_cell);
-    const uint32_t bk = bucket_of_cell(cx, cy, cz, axis_mask);
-    bucket_of[i] = bk;
-    rank[i] = atomicAdd(&bucket_count[bk], 1u);  // order inside a bucket is irrelevant downstream
+    bool first_in_bucket = false;
+    if (i < n) {
+        if (shape[i] == PHYS_SPEC_SHAPE_NONE) {
+            bucket_of[i] = kInvalid;
+        } else {
+            const float inv_cell = grid_inv_cell(ctr);
+            const v3 lo = ld3(aabb, 2 * i), hi = ld3(aabb, 2 * i + 1);
+            const int cx = cell_coord(0.5f * (lo.x + hi.x), inv_cell);
+            const int cy = cell_coord(0.5f * (lo.y + hi.y), inv_cell);
+            const int cz = cell_coord(0.5f * (lo.z + hi.z), inv_cell);
+            const uint32_t bk = bucket_of_cell(cx, cy, cz, axis_mask);
+            bucket_of[i] = bk;
+            const uint32_t r = atomicAdd(&bucket_count[bk], 1u);  // order inside a bucket is irrelevant downstream
+            rank[i] = r;
+            first_in_bucket = r == 0u;
+        }
+    }
+    // buckets in use (every bucket has exactly one first arrival): bodies per used bucket is how CROWDED the grid is, which
+    // decides the pair kernel of later updates (launch_broadphase). One fire-and-forget atomic per workgroup.
+    __shared__ uint32_t s_used;
+    if (threadIdx.x == 0) s_used = 0;
+    __syncthreads();
+    const unsigned long long firsts = __ballot(first_in_bucket);
+    if ((threadIdx.x & 63u) == 0u && firsts) atomicAdd(&s_used, (uint32_t)__popcll(firsts));
+    __syncthreads();
+    if (threadIdx.x == 0 && s_used) atomicAdd(&ctr->n_used_buckets, s_used);
 }
 
 // ---- exclusive scan of the bucket counts ----------------------------------------------------------
@@ -394,7 +410,7 @@ __global__ __launch_bounds__(kPairThreads) void k_find_pairs(const uint32_t* __r
 // comes first in the half-shell order; own-cell pairs by id order).
 constexpr int kRegX = 6, kRegY = 6, kRegZ = 5, kRegCells = kRegX * kRegY * kRegZ;  // 180
 constexpr int kBrickLanesPerBody = 4;
-constexpr int kBrickStagePerWave = 512;  // pairs staged per wave (4 KiB)
+constexpr int kBrickStagePerWave = 256;  // pairs staged per wave (2 KiB)
 
 // WHAT THE PAIR SEARCH WAITS FOR IS THE PAIR COUNTER. Same-address atomics serialise chip-wide at ~88 per microsecond, and
 // every flush of a stage is one: the one-lane-per-body kernel flushes once per wave (1M bodies: 15.6k flushes = 180 of
@@ -427,16 +443,17 @@ __device__ __forceinline__ void workgroup_flush(PairStage& st, uint32_t* s_cnt, 
     __syncthreads();  // s_cnt / s_base are reused by the next flush
 }
 
-template <int CAP /* records staged per brick */>
+// `cap` records fit the dynamic LDS of this launch (sized by the host from the largest region of an EARLIER update:
+// StepCounters::max_region; a brick with more than that walks global memory - slower, same pairs).
 __global__ __launch_bounds__(kPairThreads) void k_find_pairs_brick(const uint32_t* __restrict__ bucket_start, uint32_t n_bricks,
                                                                    GridShape g, const uint32_t* __restrict__ sorted_ids,
                                                                    const float* __restrict__ sorted_box,
                                                                    uint32_t* __restrict__ pairs, uint64_t max_pairs,
-                                                                   StepCounters* __restrict__ ctr) {
+                                                                   StepCounters* __restrict__ ctr, uint32_t cap) {
     __shared__ uint32_t stage[(kPairThreads / 64) * kBrickStagePerWave * 2];
     __shared__ uint32_t s_gstart[kRegCells];    // position of a region cell's first record in the sorted arrays
     __shared__ uint32_t s_off[kRegCells + 1];   // exclusive scan of the cells' record counts (position in s_rec)
-    __shared__ float s_rec[CAP * 7];            // {lo xyz, hi xyz, id}: odd stride, distinct banks for neighbouring records
+    extern __shared__ float s_rec[];            // cap x {lo xyz, hi xyz, id}: odd stride, distinct banks for neighbouring records
     __shared__ uint32_t s_wsum[4], s_cnt[4], s_base;
     PairStage st;
     st.lds = stage + (threadIdx.x >> 6) * kBrickStagePerWave * 2;
@@ -445,7 +462,7 @@ __global__ __launch_bounds__(kPairThreads) void k_find_pairs_brick(const uint32_
     const uint32_t sub = threadIdx.x % kBrickLanesPerBody;
     // XCD-aware deal (a label, never relied on for correctness): workgroups with equal blockIdx % 8 share an L2 and take
     // ONE contiguous eighth of the table between them, brick by brick in turn (neighbouring bricks are in flight together
-    // on one L2, and the empty bricks of a scene that fills part of its table are spread over all workgroups)
+    // on one L2). (Measured and dropped: eighths of equal BODY count taken from the bucket scan - no faster on any scene.)
     uint32_t first = blockIdx.x, last = n_bricks, step = gridDim.x;
     if (gridDim.x >= 8u && n_bricks >= 8u) {
         const uint32_t label = blockIdx.x & 7u, per = n_bricks >> 3;  // n_bricks is a power of two
@@ -453,14 +470,32 @@ __global__ __launch_bounds__(kPairThreads) void k_find_pairs_brick(const uint32_
         first = label * per + (blockIdx.x >> 3);
         last = (label + 1u) * per;
     }
+    // The bucket ranges of a brick (its own run, and the 180 cells of its region, one per lane) are asked for ONE BRICK
+    // AHEAD: what a brick then waits for is a single round trip - its records - instead of three in a row (ranges ->
+    // records, and its own bodies behind the run's bounds), with only a few workgroups per CU to hide them.
+    uint32_t nx_begin = 0, nx_end = 0, nx_c0 = 0, nx_cnt = 0;
+    auto ask = [&](uint32_t brick) {
+        nx_begin = bucket_start[brick * 64u];
+        nx_end = bucket_start[brick * 64u + 64u];
+        nx_c0 = 0; nx_cnt = 0;
+        if (threadIdx.x < (uint32_t)kRegCells) {
+            const uint32_t bx = brick & ((1u << g.sx) - 1u), by = (brick >> g.sx) & ((1u << g.sy) - 1u), bz = brick >> (g.sx + g.sy);
+            const uint32_t r = threadIdx.x;
+            const uint32_t rx = r % kRegX, ry = (r / kRegX) % kRegY, rz = r / (kRegX * kRegY);
+            const uint32_t bk = grid_bucket_masked(((bx << 2) + rx - 1u) & g.mx, ((by << 2) + ry - 1u) & g.my, ((bz << 2) + rz) & g.mz, g);
+            nx_c0 = bucket_start[bk];
+            nx_cnt = bucket_start[bk + 1] - nx_c0;
+        }
+    };
+    if (first < last) ask(first);
+    uint32_t seen_max = 0;
     for (uint32_t brick = first; brick < last; brick += step) {
-        const uint32_t own_begin = bucket_start[brick * 64u], own_end = bucket_start[brick * 64u + 64u];
+        const uint32_t own_begin = nx_begin, own_end = nx_end, my_c0 = nx_c0, my_cnt = nx_cnt;
+        if (brick + step < last) ask(brick + step);
         if (own_begin == own_end) continue;  // workgroup-uniform: an empty brick
-        const uint32_t bx = brick & ((1u << g.sx) - 1u), by = (brick >> g.sx) & ((1u << g.sy) - 1u), bz = brick >> (g.sx + g.sy);
-        const uint32_t ox = bx << 2, oy = by << 2, oz = bz << 2;
-        // the brick's own bodies: asked for now, needed after the staging (two round trips later)
         constexpr uint32_t kBodiesPerTrip = kPairThreads / kBrickLanesPerBody;
         const uint32_t n_own = own_end - own_begin;
+        // the first trip's own bodies: asked for now, needed behind the staging
         uint32_t i0 = 0;
         aabb_t b0;
         b0.lo = v3_make(0, 0, 0); b0.hi = v3_make(0, 0, 0);
@@ -470,17 +505,10 @@ __global__ __launch_bounds__(kPairThreads) void k_find_pairs_brick(const uint32_
             b0.lo = ld3(sorted_box, 2 * sidx);
             b0.hi = ld3(sorted_box, 2 * sidx + 1);
         }
-        // 1. bucket ranges of the region's cells, scanned
+        // 1. bucket ranges of the region's cells (asked for one brick ago), scanned
         {
-            uint32_t cnt = 0;
-            if (threadIdx.x < (uint32_t)kRegCells) {
-                const uint32_t r = threadIdx.x;
-                const uint32_t rx = r % kRegX, ry = (r / kRegX) % kRegY, rz = r / (kRegX * kRegY);
-                const uint32_t bk = grid_bucket_masked((ox + rx - 1u) & g.mx, (oy + ry - 1u) & g.my, (oz + rz) & g.mz, g);
-                const uint32_t c0 = bucket_start[bk], c1 = bucket_start[bk + 1];
-                s_gstart[r] = c0;
-                cnt = c1 - c0;
-            }
+            const uint32_t cnt = my_cnt;
+            if (threadIdx.x < (uint32_t)kRegCells) s_gstart[threadIdx.x] = my_c0;
             const uint32_t inc = wave_inclusive_scan(cnt);
             if ((threadIdx.x & 63u) == 63u) s_wsum[threadIdx.x >> 6] = inc;
             __syncthreads();
@@ -491,7 +519,8 @@ __global__ __launch_bounds__(kPairThreads) void k_find_pairs_brick(const uint32_
             __syncthreads();
         }
         const uint32_t total = s_off[kRegCells];
-        const bool staged = total <= (uint32_t)CAP;
+        const bool staged = total <= cap;
+        seen_max = total > seen_max ? total : seen_max;
         // 2. the region's records into LDS
         if (staged) {
             for (uint32_t q = threadIdx.x; q < total; q += kPairThreads) {
@@ -508,7 +537,11 @@ __global__ __launch_bounds__(kPairThreads) void k_find_pairs_brick(const uint32_
             }
             __syncthreads();
         }
-        // 3. the brick's own bodies, four lanes each, against the 14 cells of their half shell
+        // 3. the brick's own bodies, four lanes each, against the 14 cells of their half shell.
+        // (Measured and dropped, same pairs: (own body, candidate) tests enumerated per own CELL, sixteen cells per wave, both
+        // sides from LDS - 2.6x slower, three dependent LDS trips per cell and nothing to overlap them; a lane walking its
+        // four cells as one run, moving on the moment a cell is exhausted - fewer passes, 5-15 % slower: the cursor costs
+        // more than the passes it saves.)
         for (uint32_t base = 0; base < n_own; base += kBodiesPerTrip) {
             const uint32_t jo = base + threadIdx.x / kBrickLanesPerBody;
             const bool live = jo < n_own;
@@ -535,9 +568,8 @@ __global__ __launch_bounds__(kPairThreads) void k_find_pairs_brick(const uint32_
                 uint32_t t = 0, t_end = 0;
                 if (live && c < 14) {
                     const uint32_t rid = ((lz + (uint32_t)dz) * kRegY + (ly + (uint32_t)(dy + 1))) * kRegX + (lx + (uint32_t)(dx + 1));
-                    const uint32_t o0 = s_off[rid], o1 = s_off[rid + 1];
-                    t = staged ? o0 : s_gstart[rid];
-                    t_end = t + (o1 - o0);
+                    t = staged ? s_off[rid] : s_gstart[rid];
+                    t_end = t + (s_off[rid + 1] - s_off[rid]);
                 }
                 const bool own_cell = c == 0;
                 while (__any(t < t_end)) {
@@ -568,6 +600,8 @@ __global__ __launch_bounds__(kPairThreads) void k_find_pairs_brick(const uint32_
         workgroup_flush(st, s_cnt, &s_base, pairs, max_pairs, ctr, /*force=*/false);
     }
     workgroup_flush(st, s_cnt, &s_base, pairs, max_pairs, ctr, /*force=*/true);
+    // the largest region met: what a later update sizes its stage by (only a raise is an atomic)
+    if (threadIdx.x == 0 && seen_max > ctr->max_region) atomicMax(&ctr->max_region, seen_max);
 }
 
 // ---- slot grid (small scenes) ------------------------------------------------------------------------
@@ -883,24 +917,36 @@ void launch_broadphase(phys_world* w) {
     // throughput-bound: one lane per body does the least total work
     static const int pair_lanes_env = getenv("PHYS_DEBUG_PAIR_LANES") ? atoi(getenv("PHYS_DEBUG_PAIR_LANES")) : 0;  // measurements
     // (measured: one lane per body is the faster one already at 100k bodies - C3: 0.051 against 0.089 ms)
-    // PHYS_DEBUG_PAIR_KERNEL=body: the one-lane-(or four)-per-body kernels of rounds 1-2 (A/B measurements; same pair set)
-    static const bool body_kernel = getenv("PHYS_DEBUG_PAIR_KERNEL") != nullptr && getenv("PHYS_DEBUG_PAIR_KERNEL")[0] == 'b';
-    if (!body_kernel && !pair_lanes_env) {
+    // PHYS_DEBUG_PAIR_KERNEL=body / brick forces one (measurements; same pair set)
+    static const char* pair_kernel_env = getenv("PHYS_DEBUG_PAIR_KERNEL");
+    // The brick kernel wins where the grid is sparsely filled - lattices, stacks of aligned boxes: many bricks of few
+    // records (C4 204 -> 119 us, C5 135 -> 73) - and loses where cells are crowded (one tumbled cube sets the cell size for
+    // everybody: 1M falling cubes 89 -> 102 us, C3 51 -> 82: few bricks, each a long walk for the one workgroup that has
+    // it). Crowding = bodies per bucket in use, counted by k_cell_assign of an earlier update.
+    const bool crowded = w->hint.valid && w->hint.n_used_buckets && (uint64_t)w->n * 10ull > (uint64_t)w->hint.n_used_buckets * 21ull;
+    const bool brick = pair_kernel_env ? pair_kernel_env[0] != 'b' || pair_kernel_env[1] == 'r' : !crowded;
+    if (brick && !pair_lanes_env) {
         const uint32_t n_bricks = T >> 6;
-        // records staged per brick: 640 (36 KiB of LDS per workgroup, four per CU) covers lattices and falling piles; scenes
-        // with many pairs per body (resting piles of rotated boxes: big cells, several bodies each) take the larger stage
-        const bool dense = w->hint.valid && (uint64_t)w->hint.n_pairs > 5ull * w->n;
+        // records staged per brick: a quarter more than the largest region of an earlier update (C4: ~400 records, a pile
+        // of tumbled cubes: ~1500), 1024 while nothing is known, at most what one workgroup may have of a CU's LDS
+        constexpr uint32_t kCapMax = 5000;  // 137 KiB
+        uint32_t cap = w->hint.valid && w->hint.max_region ? w->hint.max_region + w->hint.max_region / 4 : 1024u;
+        cap = std::min(std::max((cap + 63u) & ~63u, 256u), kCapMax);
+        const size_t dyn = (size_t)cap * 28;
+        const size_t fixed = (kPairThreads / 64) * kBrickStagePerWave * 8 + kRegCells * 8 + 64;
         // persistent workgroups, as many as are resident at once (the LDS decides), never more than there are bricks
-        const uint32_t per_cu = dense ? 2u : 4u;
-        uint32_t wgs = 256u * per_cu;
+        uint32_t per_cu = (uint32_t)std::min<size_t>(5, (160 * 1024) / (((dyn + fixed) + 1023) / 1024 * 1024));
+        uint32_t wgs = 256u * std::max(per_cu, 1u);
         while (wgs > n_bricks) wgs >>= 1;
+        static bool attr_set = false;
+        if (!attr_set) {  // more than the default 64 KiB of dynamic LDS needs the attribute
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_find_pairs_brick), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+            (void)hipGetLastError();
+            attr_set = true;
+        }
         PHYS_PROF(w, PHYS_STAGE_PAIRS);
-        if (dense)
-            hipLaunchKernelGGL((k_find_pairs_brick<2048>), dim3(wgs), dim3(kPairThreads), 0, s, w->bucket_start.p, n_bricks, axis_mask,
-                               w->sorted_ids.p, w->sorted_box.p, w->pairs.p, w->max_pairs, w->counters.p);
-        else
-            hipLaunchKernelGGL((k_find_pairs_brick<640>), dim3(wgs), dim3(kPairThreads), 0, s, w->bucket_start.p, n_bricks, axis_mask,
-                               w->sorted_ids.p, w->sorted_box.p, w->pairs.p, w->max_pairs, w->counters.p);
+        hipLaunchKernelGGL(k_find_pairs_brick, dim3(wgs), dim3(kPairThreads), dyn, s, w->bucket_start.p, n_bricks, axis_mask,
+                           w->sorted_ids.p, w->sorted_box.p, w->pairs.p, w->max_pairs, w->counters.p, cap);
         return;
     }
     if (pair_lanes_env ? pair_lanes_env == 4 : n <= 65536u) {

@@ -863,6 +863,8 @@ void launch_coloring(phys_world* w) {
             w->hint.valid = true;
             w->hint.n_manifolds = c.n_manifolds;
             w->hint.n_pairs = c.n_pairs;
+            if (c.max_region) w->hint.max_region = c.max_region;
+            w->hint.n_used_buckets = c.n_used_buckets;
             w->hint.n_colors = c.n_colors;
             if (c.n_active) w->hint.n_active = c.n_active;
             if (full) w->hint.full_rounds = c.color_rounds; else w->hint.color_rounds = c.color_rounds;

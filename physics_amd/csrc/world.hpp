@@ -78,6 +78,8 @@ struct StepCounters {
     uint32_t flow_ticket;    // k_solve_flow: next (iteration, row chunk) item to hand to a workgroup
     uint32_t n_grid_ovf;     // slot grid: bodies that found their bucket's four slots taken
     uint32_t n_active;       // owned bodies with at least one manifold in this update (dynamic clusters, cluster.hip)
+    uint32_t n_used_buckets; // buckets of the sorted grid holding at least one body (k_cell_assign)
+    uint32_t max_region;     // k_find_pairs_brick: most records in the region of one brick (sizes the LDS stage of later updates)
     uint32_t cluster_arrived[2][8];  // k_solve_cluster, per attempt: workgroups that have begun (eight counters: same-address
                                      // atomics serialise chip-wide) ...
     uint32_t cluster_state[2];       // ... and the launch's one decision: 0 undecided, 1 go (all are resident), 2 called off
@@ -150,7 +152,7 @@ struct ProfScope {
 // correctness
 struct StepHint {
     bool valid = false;
-    uint32_t n_manifolds = 0, n_colors = 0, n_pairs = 0;
+    uint32_t n_manifolds = 0, n_colors = 0, n_pairs = 0, max_region = 0, n_used_buckets = 0;
     uint32_t n_active = 0;         // owned bodies with a manifold (0 = unknown)
     uint32_t color_rounds = 0;     // max over the recent INCREMENTAL updates
     uint32_t full_rounds = 0;      // rounds of the last full re-colouring (0 = unknown)
