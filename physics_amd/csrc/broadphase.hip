@@ -35,36 +35,20 @@ __device__ __forceinline__ float grid_inv_cell(const StepCounters* ctr) {
 
 __global__ __launch_bounds__(256) void k_cell_assign(uint32_t n, const float* __restrict__ aabb,
                                                      const uint32_t* __restrict__ shape,
-                                                     StepCounters* __restrict__ ctr, GridShape axis_mask,
+                                                     const StepCounters* __restrict__ ctr, GridShape axis_mask,
                                                      uint32_t* __restrict__ bucket_of, uint32_t* __restrict__ rank,
                                                      uint32_t* __restrict__ bucket_count) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    bool first_in_bucket = false;
-    if (i < n) {
-        if (shape[i] == PHYS_SPEC_SHAPE_NONE) {
-            bucket_of[i] = kInvalid;
-        } else {
-            const float inv_cell = grid_inv_cell(ctr);
-            const v3 lo = ld3(aabb, 2 * i), hi = ld3(aabb, 2 * i + 1);
-            const int cx = cell_coord(0.5f * (lo.x + hi.x), inv_cell);
-            const int cy = cell_coord(0.5f * (lo.y + hi.y), inv_cell);
-            const int cz = cell_coord(0.5f * (lo.z + hi.z), inv_cell);
-            const uint32_t bk = bucket_of_cell(cx, cy, cz, axis_mask);
-            bucket_of[i] = bk;
-            const uint32_t r = atomicAdd(&bucket_count[bk], 1u);  // order inside a bucket is irrelevant downstream
-            rank[i] = r;
-            first_in_bucket = r == 0u;
-        }
-    }
-    // buckets in use (every bucket has exactly one first arrival): bodies per used bucket is how CROWDED the grid is, which
-    // decides the pair kernel of later updates (launch_broadphase). One fire-and-forget atomic per workgroup.
-    __shared__ uint32_t s_used;
-    if (threadIdx.x == 0) s_used = 0;
-    __syncthreads();
-    const unsigned long long firsts = __ballot(first_in_bucket);
-    if ((threadIdx.x & 63u) == 0u && firsts) atomicAdd(&s_used, (uint32_t)__popcll(firsts));
-    __syncthreads();
-    if (threadIdx.x == 0 && s_used) atomicAdd(&ctr->n_used_buckets, s_used);
+    if (i >= n) return;
+    if (shape[i] == PHYS_SPEC_SHAPE_NONE) { bucket_of[i] = kInvalid; return; }
+    const float inv_cell = grid_inv_cell(ctr);
+    const v3 lo = ld3(aabb, 2 * i), hi = ld3(aabb, 2 * i + 1);
+    const int cx = cell_coord(0.5f * (lo.x + hi.x), inv_cell);
+    const int cy = cell_coord(0.5f * (lo.y + hi.y), inv_cell);
+    const int cz = cell_coord(0.5f * (lo.z + hi.z), inv_cell);
+    const uint32_t bk = bucket_of_cell(cx, cy, cz, axis_mask);
+    bucket_of[i] = bk;
+    rank[i] = atomicAdd(&bucket_count[bk], 1u);  // order inside a bucket is irrelevant downstream
 }
 
 // ---- exclusive scan of the bucket counts ----------------------------------------------------------
@@ -82,29 +66,54 @@ __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v) {
     return v;
 }
 
+// `block_used` (bucket grid only): per block, how many of its counters are non-zero = buckets in use; k_scan_block_sums
+// adds them up. Bodies per bucket in use is how CROWDED the grid is, which decides the pair kernel of later updates
+// (launch_broadphase). (Counted here, where every counter is read anyway: one atomic per workgroup of k_cell_assign -
+// 3906 of them at 1M bodies - cost that kernel 36 us.)
 __global__ __launch_bounds__(kScanThreads) void k_scan_reduce(const uint32_t* __restrict__ in, uint32_t count,
-                                                              uint32_t* __restrict__ block_sums) {
-    __shared__ uint32_t wsum[kScanThreads / 64];
+                                                              uint32_t* __restrict__ block_sums,
+                                                              uint32_t* __restrict__ block_used = nullptr) {
+    __shared__ uint32_t wsum[kScanThreads / 64], wused[kScanThreads / 64];
     const uint32_t base = blockIdx.x * kScanChunk + threadIdx.x * kScanItems;
-    uint32_t s = 0;
+    uint32_t s = 0, u = 0;
 #pragma unroll
-    for (int k = 0; k < kScanItems; ++k) s += (base + k < count) ? in[base + k] : 0u;
+    for (int k = 0; k < kScanItems; ++k) {
+        const uint32_t v = (base + k < count) ? in[base + k] : 0u;
+        s += v;
+        u += v != 0u ? 1u : 0u;
+    }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) s += (uint32_t)__shfl_xor((int)s, off, 64);
-    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = s;
+    for (int off = 32; off > 0; off >>= 1) { s += (uint32_t)__shfl_xor((int)s, off, 64); u += (uint32_t)__shfl_xor((int)u, off, 64); }
+    if ((threadIdx.x & 63) == 0) { wsum[threadIdx.x >> 6] = s; wused[threadIdx.x >> 6] = u; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        uint32_t t = 0;
-        for (int k = 0; k < kScanThreads / 64; ++k) t += wsum[k];
+        uint32_t t = 0, tu = 0;
+        for (int k = 0; k < kScanThreads / 64; ++k) { t += wsum[k]; tu += wused[k]; }
         block_sums[blockIdx.x] = t;
+        if (block_used) block_used[blockIdx.x] = tu;
     }
 }
 
 // one block: exclusive scan of the block sums in place (loops with a carry for long inputs)
-__global__ __launch_bounds__(1024) void k_scan_block_sums(uint32_t* __restrict__ sums, uint32_t count) {
+__global__ __launch_bounds__(1024) void k_scan_block_sums(uint32_t* __restrict__ sums, uint32_t count,
+                                                          const uint32_t* __restrict__ block_used = nullptr,
+                                                          StepCounters* __restrict__ ctr = nullptr) {
     __shared__ uint32_t wtot[16];
     __shared__ uint32_t carry_s;
     if (threadIdx.x == 0) carry_s = 0;
+    if (block_used) {  // buckets in use, summed over the blocks of k_scan_reduce (no atomics on the way)
+        uint32_t u = 0;
+        for (uint32_t k = threadIdx.x; k < count; k += 1024) u += block_used[k];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) u += (uint32_t)__shfl_xor((int)u, off, 64);
+        if ((threadIdx.x & 63) == 0) wtot[threadIdx.x >> 6] = u;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t t = 0;
+            for (int k = 0; k < 16; ++k) t += wtot[k];
+            ctr->n_used_buckets = t;
+        }
+    }
     __syncthreads();
     for (uint32_t base = 0; base < count; base += 1024) {
         const uint32_t idx = base + threadIdx.x;
@@ -793,7 +802,7 @@ int32_t collision_alloc(phys_world* w) {
     PHYS_HIP_TRY(w->bucket_of.resize(n));
     PHYS_HIP_TRY(w->bucket_cursor.resize(n));  // rank of each body inside its bucket
     PHYS_HIP_TRY(w->bucket_start.resize((size_t)T + 1));
-    PHYS_HIP_TRY(w->scan_block_sums.resize(std::max<size_t>((T + kScanChunk - 1) / kScanChunk + 1, 64)));
+    PHYS_HIP_TRY(w->scan_block_sums.resize(2 * std::max<size_t>((T + kScanChunk - 1) / kScanChunk + 1, 64)));  // sums | buckets in use
     PHYS_HIP_TRY(w->sorted_ids.resize(n));
     PHYS_HIP_TRY(w->slot_ids.resize((size_t)kSlotsPerBucket * T));
     PHYS_HIP_TRY(w->slot_box.resize((size_t)6 * kSlotsPerBucket * T));
@@ -885,8 +894,9 @@ void build_sorted_grid(phys_world* w) {
         hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(kScanSmallThreads), 0, s, w->bucket_count.p, T, w->bucket_start.p);
     } else {
         const uint32_t nblk = (T + kScanChunk - 1) / kScanChunk;
-        { PHYS_PROF(w, PHYS_STAGE_GRID); hipLaunchKernelGGL(k_scan_reduce, dim3(nblk), dim3(kScanThreads), 0, s, w->bucket_count.p, T, w->scan_block_sums.p); }
-        { PHYS_PROF(w, PHYS_STAGE_GRID); hipLaunchKernelGGL(k_scan_block_sums, dim3(1), dim3(1024), 0, s, w->scan_block_sums.p, nblk); }
+        uint32_t* used = w->scan_block_sums.p + (w->scan_block_sums.n / 2);  // second half of the buffer
+        { PHYS_PROF(w, PHYS_STAGE_GRID); hipLaunchKernelGGL(k_scan_reduce, dim3(nblk), dim3(kScanThreads), 0, s, w->bucket_count.p, T, w->scan_block_sums.p, used); }
+        { PHYS_PROF(w, PHYS_STAGE_GRID); hipLaunchKernelGGL(k_scan_block_sums, dim3(1), dim3(1024), 0, s, w->scan_block_sums.p, nblk, (const uint32_t*)used, w->counters.p); }
         { PHYS_PROF(w, PHYS_STAGE_GRID); hipLaunchKernelGGL(k_scan_final, dim3(nblk), dim3(kScanThreads), 0, s, w->bucket_count.p, T, w->scan_block_sums.p,
                            w->bucket_start.p); }
     }
