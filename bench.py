@@ -572,10 +572,11 @@ def main():
             out["config"]["cross_slab_contacts"] = (
                 "broad phase only: candidate pairs across slab faces are found and counted (AABB halo exchange)"
                 if not rig.halo.before_update else
-                "solved: every rank sees its neighbours' boundary bodies as kinematic ghost bodies (96-byte records, one "
-                "all-gather per step, before the update) and collides / solves its own bodies against them; a contact "
-                "across a plane is solved once per side against an immovable copy of the other body, so the N-rank run "
-                "approximates, and is not bit-identical to, the single-world simulation cut in N")
+                "solved with a shared impulse: every rank sees its neighbours' boundary bodies as DYNAMIC ghost bodies (96-byte "
+                "records with mass and inverse inertia, exchanged before the update) and solves the two-body contact on its "
+                "side from the same state as the neighbour does on his, each keeping its own body's half; exact for an "
+                "isolated pair (momentum to 1e-6, tests/test_gpu_ghosts.py), an approximation of the single-world run in a "
+                "pile (a rank sees the neighbour's bodies only as far as its ghosts reach), never its bits")
         if "roofline" in rec:
             roof = rec["roofline"]
             if not sharded:

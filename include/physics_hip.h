@@ -259,15 +259,19 @@ int32_t phys_get_cross_pairs(phys_world* w, uint32_t* pairs_out /*2*cap*/, uint6
 /* Sharded worlds with contacts across the cut planes (SURVEY §8 rows E + N4; no reference counterpart: the reference is
  * one thread on one CPU). A world created with phys_config.max_ghosts > 0 keeps max_ghosts GHOST slots behind its owned
  * bodies. Before every update the ranks exchange the full state of their boundary bodies - a 96-byte record {pos, rot,
- * lin vel, ang vel, half extent, shape, global id} of every owned body within `reach` of a slab face - and every rank
- * places the neighbours' records that lie within `reach` of ITS slab into its ghost slots. A ghost is a kinematic body
- * (inverse mass and inverse inertia 0, velocity as exchanged): the ordinary broad phase, narrow phase and solver of the
- * update then see it like any other body, so an owned body collides with and is pushed by bodies across the plane; the
- * ghost itself is never moved here (its owner moves it, seeing THIS rank's boundary bodies as ghosts in turn). What this
- * is not: a contact across the plane is solved twice, once per side, each against an immovable copy of the other body
- * (no shared impulse), so momentum across a cut plane is conserved only approximately. Ghost-ghost pairs and
- * ghost-ground contacts are skipped. Slot order is a function of the records alone (both compactions are prefix sums,
- * not atomics), so a sharded run repeats bit for bit.
+ * lin vel, ang vel, half extent, shape, global id, inverse mass, inverse inertia diagonal} of every owned body within
+ * `reach` of a slab face - and every rank places the neighbours' records that lie within `reach` of ITS slab into its
+ * ghost slots. A ghost is a DYNAMIC body of the receiving world for the length of one update: its owner's mass and
+ * inertia, this update's gravity, contacts with the ground, with other ghosts and with owned bodies. A contact between an
+ * owned body and a body across the plane is therefore solved as the two-body contact it is, on BOTH sides of the plane
+ * from the same state, and each side keeps its own body's half of the outcome (what the update did to the ghost is
+ * forgotten at the next exchange): for an isolated pair the two halves are equal and opposite up to float rounding
+ * (momentum across the plane conserved to ~1e-6), in a pile each side also sees its body's other contacts, which the
+ * neighbour sees only as far as its ghosts reach - the N-rank run approximates the single-world run, it does not
+ * reproduce its bits. (Round 2 placed ghosts as KINEMATIC bodies - an impact on a ghost was an impact on a moving wall,
+ * 2 m v instead of the two-body impulse; a body whose world-frame inertia tensor is not diagonal still crosses that way:
+ * the record holds a diagonal.) Slot order is a function of the records alone (both compactions are prefix sums, not
+ * atomics), so a sharded run repeats bit for bit.
  *   phys_set_slab            this rank's x-interval and the reach (>= the largest bounding diameter + margin on any rank)
  *   phys_halo_pack_bodies    owned boundary bodies -> 96-byte records in DEVICE memory (unused slots: global id 0xFFFFFFFF)
  *   phys_halo_unpack_ghosts  gathered records (device) -> ghost slots; [skip_first, skip_first+skip_count) = own block

@@ -240,7 +240,8 @@ __global__ __launch_bounds__(256) void k_halo_pack_bodies(uint32_t n_owned, cons
                                                           const float* __restrict__ rot, const float* __restrict__ vel,
                                                           const float* __restrict__ half_extent,
                                                           const uint32_t* __restrict__ shape,
-                                                          const uint32_t* __restrict__ global_id, float x_lo, float x_hi,
+                                                          const uint32_t* __restrict__ global_id,
+                                                          const float* __restrict__ inv_inertia /* 9 per body */, float x_lo, float x_hi,
                                                           float reach, const uint32_t* __restrict__ block_counts,
                                                           BodyRecord* __restrict__ out, uint32_t cap, StepCounters* ctr) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
@@ -256,8 +257,13 @@ __global__ __launch_bounds__(256) void k_halo_pack_bodies(uint32_t n_owned, cons
     r.q[1] = make_float4(q.y, q.z, q.w, bv.v.x);
     r.q[2] = make_float4(bv.v.y, bv.v.z, bv.w.x, bv.w.y);
     r.q[3] = make_float4(bv.w.z, he.x, he.y, he.z);
-    r.q[4] = make_float4(__uint_as_float(shape[i]), __uint_as_float(global_id[i]), 0.0f, 0.0f);
-    r.q[5] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    // mass properties travel too: the neighbour solves its contacts with this body as a DYNAMIC body (the impulse of a contact
+    // across the plane is then the two-body impulse on both sides, not an impact on an immovable wall). A diagonal inverse
+    // inertia fits the record; a full tensor is flagged and that body crosses as a kinematic one, as in round 2.
+    const float* I = inv_inertia + 9 * (size_t)i;
+    const bool full = I[1] != 0.0f || I[2] != 0.0f || I[3] != 0.0f || I[5] != 0.0f || I[6] != 0.0f || I[7] != 0.0f;
+    r.q[4] = make_float4(__uint_as_float(shape[i]), __uint_as_float(global_id[i]), bv.inv_mass, __uint_as_float(full ? 1u : 0u));
+    r.q[5] = make_float4(I[0], I[4], I[8], 0.0f);
 #pragma unroll
     for (int k = 0; k < 6; ++k) out[slot].q[k] = r.q[k];
 }
@@ -276,6 +282,7 @@ __global__ __launch_bounds__(256) void k_halo_unpack(uint32_t n_records, uint32_
                                                      uint32_t max_ghosts, float* __restrict__ pos, float* __restrict__ rot,
                                                      float* __restrict__ vel, float* __restrict__ half_extent,
                                                      uint32_t* __restrict__ shape, uint32_t* __restrict__ global_id,
+                                                     float* __restrict__ inv_inertia, float* __restrict__ inv_inertia_diag,
                                                      StepCounters* ctr) {
     const uint32_t k = blockIdx.x * 256u + threadIdx.x;
     const bool take = ghost_record(k, n_records, skip_first, skip_count, rec, x_lo, x_hi, reach);
@@ -283,15 +290,26 @@ __global__ __launch_bounds__(256) void k_halo_unpack(uint32_t n_records, uint32_
     if (!take) return;
     if (slot >= max_ghosts) { flag_overflow(ctr, 8u); return; }
     const uint32_t i = n_owned + slot;
-    float4 q[5];
+    float4 q[6];
 #pragma unroll
-    for (int j = 0; j < 5; ++j) q[j] = rec[k].q[j];
+    for (int j = 0; j < 6; ++j) q[j] = rec[k].q[j];
     st3(pos, i, v3_make(q[0].x, q[0].y, q[0].z));
     reinterpret_cast<float4*>(rot)[i] = make_float4(q[0].w, q[1].x, q[1].y, q[1].z);
+    // A ghost is a DYNAMIC body of this world for the length of one update: it has its owner's mass and (diagonal) inverse
+    // inertia, feels this update's gravity like at home (the record holds its velocity BEFORE the owner's velocity half),
+    // rests on the ground and on other ghosts, and a contact between it and an owned body is solved as the two-body
+    // contact it is - on both sides of the plane alike, each side keeping its own body's half of the outcome. Its state
+    // here is forgotten when the next exchange brings the owner's. A body with a full inertia tensor (flagged by the
+    // sender: the record holds a diagonal) stays kinematic: inverse mass and inertia 0, F / m = 0.
+    const bool kinematic = __float_as_uint(q[4].w) != 0u || !(q[4].z > 0.0f);
     BodyVel bv;
-    bv.v = v3_make(q[1].w, q[2].x, q[2].y); bv.inv_mass = 0.0f;                 // kinematic: nothing here can push it,
-    bv.w = v3_make(q[2].z, q[2].w, q[3].x); bv.mass = __uint_as_float(0x7F800000u);  // F / m = 0 in the velocity half
+    bv.v = v3_make(q[1].w, q[2].x, q[2].y); bv.inv_mass = kinematic ? 0.0f : q[4].z;
+    bv.w = v3_make(q[2].z, q[2].w, q[3].x); bv.mass = kinematic ? __uint_as_float(0x7F800000u) : 1.0f / q[4].z;
     st_vel(vel, i, bv);
+    const float dx = kinematic ? 0.0f : q[5].x, dy = kinematic ? 0.0f : q[5].y, dz = kinematic ? 0.0f : q[5].z;
+    float* I = inv_inertia + 9 * (size_t)i;
+    I[0] = dx; I[1] = 0.0f; I[2] = 0.0f; I[3] = 0.0f; I[4] = dy; I[5] = 0.0f; I[6] = 0.0f; I[7] = 0.0f; I[8] = dz;
+    reinterpret_cast<float4*>(inv_inertia_diag)[i] = make_float4(dx, dy, dz, 0.0f);
     st3(half_extent, i, v3_make(q[3].y, q[3].z, q[3].w));
     shape[i] = __float_as_uint(q[4].x);
     global_id[i] = __float_as_uint(q[4].y);
@@ -324,7 +342,7 @@ int32_t halo_pack_bodies_faces(phys_world* w, void* dev_out, uint64_t cap, float
         hipLaunchKernelGGL(k_halo_count<0>, g, b, 0, w->stream, n, n, w->pos.p, w->shape.p, (const BodyRecord*)nullptr, 0u, 0u,
                            x_lo, x_hi, w->slab_reach, w->halo_block_counts.p);
         hipLaunchKernelGGL(k_halo_pack_bodies, g, b, 0, w->stream, n, w->pos.p, w->rot.p, w->vel.p, w->half_extent.p, w->shape.p,
-                           w->global_id.p, x_lo, x_hi, w->slab_reach, w->halo_block_counts.p, (BodyRecord*)dev_out,
+                           w->global_id.p, w->inv_inertia.p, x_lo, x_hi, w->slab_reach, w->halo_block_counts.p, (BodyRecord*)dev_out,
                            (uint32_t)cap, w->counters.p);
     }
     PHYS_HIP_TRY(hipGetLastError());
@@ -349,7 +367,8 @@ int32_t halo_unpack_ghosts(phys_world* w, const void* dev_records, uint64_t n_re
                            w->slab_lo, w->slab_hi, w->slab_reach, w->halo_block_counts.p);
         hipLaunchKernelGGL(k_halo_unpack, g, b, 0, w->stream, (uint32_t)n_records, (uint32_t)skip_first, (uint32_t)skip_count,
                            (const BodyRecord*)dev_records, w->slab_lo, w->slab_hi, w->slab_reach, w->halo_block_counts.p, n_owned, G,
-                           w->pos.p, w->rot.p, w->vel.p, w->half_extent.p, w->shape.p, w->global_id.p, w->counters.p);
+                           w->pos.p, w->rot.p, w->vel.p, w->half_extent.p, w->shape.p, w->global_id.p, w->inv_inertia.p,
+                           w->inv_inertia_diag.p, w->counters.p);
     }
     PHYS_HIP_TRY(hipGetLastError());
     w->aabbs_valid = false;

@@ -34,8 +34,9 @@ __device__ __forceinline__ geom_t load_geom(uint32_t i, const float* __restrict_
 // halves), 256 for everything else (launch_narrowphase)
 template <int kNpThreads>
 __global__ __launch_bounds__(kNpThreads) void k_narrowphase(
-    uint32_t n_ground /* bodies tested against the plane (0 = no ground) */, uint32_t n_owned /* bodies at or beyond this
-    index are ghosts of a sharded world: a pair of two ghosts belongs to other ranks */, const uint32_t* __restrict__ pairs,
+    uint32_t n_ground /* bodies tested against the plane (0 = no ground) */, uint32_t n_owned /* pairs whose FIRST body is at
+    or beyond this index are skipped (= all body slots: the ghosts of a sharded world collide like everybody else) */,
+    const uint32_t* __restrict__ pairs,
     uint64_t max_pairs, const float* __restrict__ geo /* 16 floats per body: {pos, shape} {rot} {half extent, AABB lo.y} */,
     float margin, float ground, uint64_t max_manifolds, uint32_t* __restrict__ man_a, uint32_t* __restrict__ man_b,
     uint32_t* __restrict__ man_color, float* __restrict__ man_geo /* 32 floats per manifold */,
@@ -87,7 +88,7 @@ __global__ __launch_bounds__(kNpThreads) void k_narrowphase(
         } else if (idx < total) {
             const uint2 pr = reinterpret_cast<const uint2*>(pairs)[idx - n_ground];
             a = pr.x; b = pr.y;
-            if (a < n_owned) {  // a < b: both are ghosts iff a is one
+            if (a < n_owned) {
                 // the colour-table entry this pair would keep its colour from (a random 16-byte read): asked for NOW, so
                 // that it travels while the shapes are fetched and tested instead of being one more dependent round trip
                 // behind the emission below (nearly every candidate pair of a resting pile becomes a manifold)
@@ -717,8 +718,10 @@ __global__ __launch_bounds__(kColorThreads) void k_color_small(uint64_t max_mani
 void launch_narrowphase(phys_world* w) {
     const uint32_t n = (uint32_t)w->n;
     if (n == 0) return;
-    const uint32_t n_owned = (uint32_t)w->n_owned;  // ghosts rest on their owner's ground
-    const uint32_t n_ground = (w->cfg.flags & PHYS_FLAG_GROUND_PLANE) ? n_owned : 0u;
+    // ghost bodies of a sharded world (slots behind the owned bodies) are dynamic bodies of this world for one update
+    // (halo.hip k_halo_unpack): they rest on the ground and on each other like everybody else
+    const uint32_t n_owned = n;
+    const uint32_t n_ground = (w->cfg.flags & PHYS_FLAG_GROUND_PLANE) ? n : 0u;
     const uint64_t work = (uint64_t)n_ground + w->max_pairs;
     // colouring state of the step: used masks + three rotating priority buffers (one memset); the narrow
     // phase publishes round 0's per-body maxima as it emits manifolds
