@@ -648,8 +648,11 @@ __global__ __launch_bounds__(kClusterThreads, DIAG ? kClusterPerCuDiag : kCluste
                 have = lit < iterations && !dead;
                 if (have) fetch();
             }
-            // LDS velocities of this colour are in place before the next colour reads them (see above: not __syncthreads)
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            // LDS velocities of this colour are in place before the next colour reads them (see above: not __syncthreads).
+            // A colour in which this cluster owns no row wrote nothing: no barrier (the barrier orders this workgroup's LDS
+            // traffic only - other workgroups are waited for through the granules' tags; the trailing colours of a
+            // colouring are sparse, most clusters have nothing in them)
+            if (seg_hi != s_seg[col]) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         }
         if (++col == n_colors) { col = 0u; ++it; }
     }
