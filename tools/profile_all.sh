@@ -17,7 +17,13 @@ for wl in "$@"; do
     timeout -k 10 400 rocprofv3 --pmc $c --output-format csv -d $out/pmc_${wl}_$c -- python3 bench.py $args > $out/pmc_${wl}_$c.log 2>&1
     echo "pmc $wl $c done"
   done
-  # keep the merged output small: the per-dispatch tables of the window are all that is needed
-  find $out -name "*agent_info.csv" -delete
+  # cut the timed window out on the box (the raw per-dispatch tables of eight workloads exceed what gpurun copies
+  # back): profiles/r3_<wl>_window.json + the rocprofv3 --stats kernel summary of the same command
+  python3 tools/profile_window.py $wl $out > $out/window_cut_$wl.log 2>&1 || cat $out/window_cut_$wl.log
+  mkdir -p gpurun_out/profiles_r3
+  cp profiles/r3_${wl}_window.json gpurun_out/profiles_r3/ 2>/dev/null || true
+  stats=$(find $out/trace_$wl -name "*kernel_stats.csv" | head -1)
+  [ -n "$stats" ] && cp "$stats" gpurun_out/profiles_r3/r3_${wl}_kernel_stats.csv
+  rm -rf $out/trace_$wl $out/pmc_${wl}_FETCH_SIZE $out/pmc_${wl}_WRITE_SIZE
 done
-du -sh $out
+du -sh $out gpurun_out/profiles_r3
