@@ -386,7 +386,9 @@ def cpu_baseline(scene, state, window_start, sample_steps, budget_s=14.0):
     # additionally the OpenMP variant of the same oracle (same bits for any thread count) on the host
     # cores this process may use, at most 16 (the CPU share of one GPU on the bench boxes)
     cores = min(len(os.sched_getaffinity(0)), 16)
-    km, dt_mt = timed(cores) if cores > 1 and not scene.constraints else (k1, dt)  # (the constraint path has no OpenMP loops)
+    if scene.constraints:
+        cores = 1  # the reference path (gravity, constraints, CG, integrate) has no OpenMP loops: one figure
+    km, dt_mt = timed(cores) if cores > 1 else (k1, dt)
     extra = {}
     if scene.constraints and cg_iters[0]:
         extra = {"cg_iterations_per_update": round(cg_iters[0] / k1, 2),
