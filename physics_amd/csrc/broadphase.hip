@@ -948,11 +948,11 @@ void launch_broadphase(phys_world* w) {
         uint32_t per_cu = (uint32_t)std::min<size_t>(5, (160 * 1024) / (((dyn + fixed) + 1023) / 1024 * 1024));
         uint32_t wgs = 256u * std::max(per_cu, 1u);
         while (wgs > n_bricks) wgs >>= 1;
-        static bool attr_set = false;
-        if (!attr_set) {  // more than the default 64 KiB of dynamic LDS needs the attribute
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_find_pairs_brick), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-            (void)hipGetLastError();
-            attr_set = true;
+        static bool attr_set[64] = {};  // per device (function attributes are): more than 64 KiB of dynamic LDS needs it
+        if (!attr_set[w->device & 63]) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_find_pairs_brick), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) == hipSuccess)
+                attr_set[w->device & 63] = true;
+            else (void)hipGetLastError();
         }
         PHYS_PROF(w, PHYS_STAGE_PAIRS);
         hipLaunchKernelGGL(k_find_pairs_brick, dim3(wgs), dim3(kPairThreads), dyn, s, w->bucket_start.p, n_bricks, axis_mask,

@@ -673,15 +673,6 @@ void launch_solve_cluster(phys_world* w, void* row_all, uint64_t cap, float fric
     ClusterRowArrays rows;
     rows.all = (float4*)row_all; rows.cap = cap;
     const size_t lds = cluster_lds_bytes(w->cluster_slots);
-    static bool attr_set = false;
-    if (!attr_set) {  // more than the default 64 KiB of dynamic LDS needs the attribute (once per kernel)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_solve_cluster<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_solve_cluster<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_solve_cluster<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_solve_cluster<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipGetLastError();
-        attr_set = true;
-    }
     const dim3 g(w->cluster_count), b(kClusterThreads);
     // Every workgroup of this launch must be resident at once, which the grid size guarantees only if no OTHER launch of
     // this kernel shares the device: two worlds of one process (two streams) would each get part of the CUs and wait for
@@ -690,6 +681,20 @@ void launch_solve_cluster(phys_world* w, void* row_all, uint64_t cap, float fric
     static std::mutex chain_lock;
     static hipEvent_t chain_event[64] = {};
     std::lock_guard<std::mutex> hold(chain_lock);
+    {
+        // more than the default 64 KiB of dynamic LDS needs the attribute: once per kernel AND DEVICE (function attributes
+        // are per device: a world on a second device of this process - phys_comm_create_local - needs its own), under the
+        // lock (two host threads), the current device being the world's (ENTER of the ABI call) - ADVICE r2
+        static bool attr_set[64] = {};
+        if (!attr_set[w->device & 63]) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_solve_cluster<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_solve_cluster<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_solve_cluster<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_solve_cluster<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) { (void)hipGetLastError(); set_error(std::string("hipFuncSetAttribute(k_solve_cluster): ") + hipGetErrorString(e)); }
+            else attr_set[w->device & 63] = true;
+        }
+    }
     hipEvent_t& ev = chain_event[w->device & 63];
     if (ev) (void)hipStreamWaitEvent(w->stream, ev, 0);
     else (void)hipEventCreateWithFlags(&ev, hipEventDisableTiming);

@@ -42,7 +42,8 @@ __global__ __launch_bounds__(kNpThreads) void k_narrowphase(
     uint32_t* __restrict__ man_color, float* __restrict__ man_geo /* 32 floats per manifold */,
     uint64_t* __restrict__ man_prio, unsigned long long* __restrict__ used,
     unsigned long long* __restrict__ top0, ulonglong2* __restrict__ cache /* persistent colour table (kernels.hpp) */,
-    uint32_t cache_mask /* 0 = keep nothing this update */, uint32_t stamp /* of this update */,
+    uint32_t cache_mask /* 0 = keep nothing this update */, uint32_t early_probe /* ask for the table entry before the shapes
+    are tested */, uint32_t stamp /* of this update */,
     uint32_t* __restrict__ unc_list /* ids of the manifolds that did not keep a colour: round 0 of the colouring */,
     StepCounters* __restrict__ ctr) {
     // per-wave totals of a trip, in two sets used alternately: a wave may start the next trip (and post its totals) while
@@ -92,7 +93,10 @@ __global__ __launch_bounds__(kNpThreads) void k_narrowphase(
                 // the colour-table entry this pair would keep its colour from (a random 16-byte read): asked for NOW, so
                 // that it travels while the shapes are fetched and tested instead of being one more dependent round trip
                 // behind the emission below (nearly every candidate pair of a resting pile becomes a manifold)
-                if (cache_mask) {
+                // (only where most candidate pairs DO become manifolds: a stack of aligned boxes has three sliver pairs for
+                // every contact since the sliver rule, and three wasted 64-byte line fetches out of a 100+ MB table for
+                // every useful one - launch_narrowphase decides from the counts of an earlier update)
+                if (cache_mask && early_probe) {
                     early_h = (uint32_t)(color_priority(a, b) >> 20) & cache_mask;
                     early = cache[early_h];
                     have_early = true;
@@ -728,6 +732,10 @@ void launch_narrowphase(phys_world* w) {
     // persistent colouring: colours of the previous update are kept (contact_solve.h)
     const uint32_t cache_mask = w->ctab_valid ? w->ctab_mask : 0u;
     const uint32_t stamp = (uint32_t)w->color_epoch + 1u;  // never 0xFFFFFFFF (the stamp of an empty slot) in a world's life
+    // the colour-table entry of a pair is asked for ahead of the shape test where at least half of the pairs become manifolds
+    static const char* probe_env = getenv("PHYS_DEBUG_NP_EARLY_PROBE");  // 0 / 1 forces it (measurements; same bits)
+    const uint32_t early_probe = probe_env ? (uint32_t)(probe_env[0] == '1')
+                                           : (uint32_t)(!w->hint.valid || 2ull * w->hint.n_manifolds >= (uint64_t)w->hint.n_pairs);
     PHYS_PROF(w, PHYS_STAGE_NARROW);
 #define PHYS_NP_LAUNCH(T)                                                                                              \
     do {                                                                                                               \
@@ -737,7 +745,7 @@ void launch_narrowphase(phys_world* w) {
                            w->max_pairs, w->geo.p, w->cfg.contact_margin, \
                            w->cfg.ground_height, w->max_manifolds, w->man_a.p, w->man_b.p,                             \
                            w->man_color.p, w->man_geo.p, w->man_prio.p, w->color_state.p,                              \
-                           w->color_state.p + n, reinterpret_cast<ulonglong2*>(w->ctab.p), cache_mask, stamp,          \
+                           w->color_state.p + n, reinterpret_cast<ulonglong2*>(w->ctab.p), cache_mask, early_probe, stamp, \
                            w->unc_list.p, w->counters.p);                                                              \
     } while (0)
     static const int np_threads_env = getenv("PHYS_DEBUG_NP_THREADS") ? atoi(getenv("PHYS_DEBUG_NP_THREADS")) : 0;  // measurements
