@@ -163,7 +163,10 @@ class Rig:
 
     def make_world(self):
         import physics_amd
-        w = physics_amd.World(self.scene.config(device=self.local_rank))
+        # the bench has its GPU to itself (one rank per GPU, nothing else on it): PHYS_FLAG_EXCLUSIVE_GPU, stated in
+        # config.flags_note (the default - a guarded start of the cluster solver's launch - costs 0.06-0.09 ms per update)
+        flags = self.scene.flags | (0 if self.rehearsal else physics_amd.FLAG_EXCLUSIVE_GPU)
+        w = physics_amd.World(self.scene.config(device=self.local_rank, flags=flags))
         self.scene.populate(w)
         if self.halo is not None:
             self.halo.attach(w, self.scene)
@@ -558,6 +561,9 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": rig.scene.name, "n_bodies": rec["n_bodies"], "bodies_per_gpu": rig.scene.n,
                        "solver_iterations": rig.iters, "dt_nanos": DT_NANOS, "preroll_steps": preroll,
+                       "flags_note": "PHYS_FLAG_EXCLUSIVE_GPU: nothing else runs on the benchmark's GPU, so the cluster solver "
+                                     "skips the all-or-nothing count of its workgroups (the default, for hosts that share the "
+                                     "GPU with a renderer: +0.06-0.09 ms per update on C5 / the 1M cubes)",
                        "timed_window": f"steps {preroll + args.warmup}..{preroll + args.warmup + args.steps} of the trajectory",
                        "sharding": "none" if not sharded else (
                            f"x-slabs x{n_gpus}, one process per GPU; " +

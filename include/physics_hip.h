@@ -52,13 +52,16 @@ extern "C" {
 #define PHYS_FLAG_BROADPHASE_ONLY 0x8u /* with COLLISIONS: stop after the candidate-pair list */
 #define PHYS_FLAG_SOLVER_PER_COLOR 0x10u /* contact solver as one launch per colour class instead of the single-launch
                                             dataflow kernel; same order of updates per body, bit-identical results */
-#define PHYS_FLAG_SHARED_GPU 0x20u       /* other work (another stream of the application, another process) may run on
-                                            this GPU beside phys_update. The cluster solver - one launch whose workgroups
-                                            must all be resident - then starts all-or-nothing (every workgroup is counted
-                                            in before anything is written; a launch that does not fit is called off and
-                                            tried again): ~0.06 ms per update. Implied when the process holds several
-                                            worlds on one device. Same results either way. */
-
+#define PHYS_FLAG_SHARED_GPU 0x20u       /* kept for callers of ABI 2: the guarded start it asked for is the DEFAULT now */
+#define PHYS_FLAG_EXCLUSIVE_GPU 0x80u    /* nothing else runs on this GPU while phys_update does (no other stream of the
+                                            application, no other process). The cluster solver - one launch whose
+                                            workgroups must all be resident - by default starts all-or-nothing (every
+                                            workgroup is counted in before anything is written; a launch that does not
+                                            fit beside other streams' kernels is called off and tried again: ~0.06-0.09
+                                            ms per update); with this flag it skips the count. A world that sets it on a
+                                            GPU that IS shared may spin into the solver's 3 s time-out (PHYS_ERR_HIP at
+                                            phys_sync). Several worlds of one process on a device are always guarded.
+                                            Same results either way. */
 #define PHYS_FLAG_SOLVER_CLUSTER 0x40u    /* contact solver: the cluster kernel (body velocities resident in LDS per spatial
                                             cluster, one launch) wherever the scene admits it (>= 32768 bodies, > 40k
                                             manifolds), instead of only where it is the fastest path (>= 200k manifolds).

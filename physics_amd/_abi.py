@@ -21,6 +21,7 @@ FLAG_COLLISIONS, FLAG_GROUND_PLANE, FLAG_EXACT_ROTATION, FLAG_BROADPHASE_ONLY = 
 FLAG_SOLVER_PER_COLOR = 16
 FLAG_SHARED_GPU = 32
 FLAG_SOLVER_CLUSTER = 64
+FLAG_EXCLUSIVE_GPU = 128
 GROUND_ID = 0xFFFFFFFF
 
 f32p = C.POINTER(C.c_float)

@@ -445,7 +445,7 @@ int32_t phys_sync(phys_world* w) {
                                    std::to_string(g[6] & 1u) + "/" + std::to_string((g[6] >> 1) & 1u) + ", modes " +
                                    std::to_string((g[6] >> 4) & 3u) + "/" + std::to_string((g[6] >> 8) & 3u) + ", iteration " +
                                    std::to_string((g[7] >> 8) & 0xFFu) + ", colour " + std::to_string(g[7] & 0xFFu) +
-                                   ". If other work shares this GPU with phys_update, create the world with PHYS_FLAG_SHARED_GPU").c_str());
+                                   ". If other work shares this GPU with phys_update, create the world WITHOUT PHYS_FLAG_EXCLUSIVE_GPU").c_str());
     }
     if (bits & 16u)
         return fail(PHYS_ERR_HIP, "contact solver hand-off timed out (k_solve_flow) in a step since the last phys_sync; "

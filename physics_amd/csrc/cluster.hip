@@ -598,7 +598,7 @@ __global__ __launch_bounds__(kClusterThreads, DIAG ? kClusterPerCuDiag : kCluste
                 if (GUARDED && late && atomicCAS(&ctr->debug[0], 0u, 0xC1u) == 0u) {
                     // the first lane to give up says what it waited for (outside the poll loop, and without reading the granules again:
                     // cold code in the row path costs the whole kernel 1-2 % at its register limit - so only in the guarded variant,
-                    // where a time-out is a defect; in the other one it means the GPU was shared without PHYS_FLAG_SHARED_GPU)
+                    // where a time-out is a defect; in the other one it means PHYS_FLAG_EXCLUSIVE_GPU was set on a GPU that is shared)
                     ctr->debug[1] = cluster | (gridDim.x << 16);
                     ctr->debug[2] = d_row; ctr->debug[3] = h.x; ctr->debug[4] = h.y;
                     ctr->debug[5] = (tA & 0xFFFFu) | (tB << 16);
@@ -700,10 +700,11 @@ void launch_solve_cluster(phys_world* w, void* row_all, uint64_t cap, float fric
     else (void)hipEventCreateWithFlags(&ev, hipEventDisableTiming);
     struct Record { hipEvent_t e; hipStream_t s; ~Record() { if (e) (void)hipEventRecord(e, s); } } record{ev, w->stream};
     // ... and the all-or-nothing start inside the kernel covers what runs beside a launch from other streams - where that
-    // can happen: several worlds of this process on the device, or PHYS_FLAG_SHARED_GPU. A world alone on its GPU starts
-    // every launch on an idle device (its own kernels run one after the other) and skips the count (C5: 0.09 ms, 1M cubes:
-    // 0.06 ms per update).
-    const bool guarded = worlds_on_device(w->device) > 1 || (w->cfg.flags & PHYS_FLAG_SHARED_GPU) != 0u;
+    // can happen: ANYWHERE, unless the caller says the GPU is this world's alone (PHYS_FLAG_EXCLUSIVE_GPU: its own kernels
+    // run one after the other, every launch starts on an idle device, the count - C5: 0.09 ms, 1M cubes: 0.06 ms per
+    // update - is skipped). The guarded start is the default since round 3: a drop-in behind a render loop shares its GPU
+    // with the renderer, and the unguarded launch's failure mode there is a 3 s spin.
+    const bool guarded = worlds_on_device(w->device) > 1 || !(w->cfg.flags & PHYS_FLAG_EXCLUSIVE_GPU) || (w->cfg.flags & PHYS_FLAG_SHARED_GPU) != 0u;
     const uint32_t kAttempts = guarded ? 2u : 1u;
     for (uint32_t attempt = 0; attempt < kAttempts; ++attempt) {
         const uint32_t last = attempt + 1 == kAttempts ? 1u : 0u;

@@ -7,7 +7,7 @@ benchmark scenes; reference-parity tests keep (0,0,1.5)). Jitter comes from spli
 """
 import numpy as np
 
-from ._abi import (FLAG_BROADPHASE_ONLY, FLAG_COLLISIONS, FLAG_GROUND_PLANE, SHAPE_BOX, SHAPE_SPHERE,
+from ._abi import (FLAG_BROADPHASE_ONLY, FLAG_COLLISIONS, FLAG_EXCLUSIVE_GPU, FLAG_GROUND_PLANE, SHAPE_BOX, SHAPE_SPHERE,
                    default_config)
 
 DT_NANOS = 16_666_667  # Duration::from_nanos -> as_secs_f32 = 0.016666668 (quirk Q7)

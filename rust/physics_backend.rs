@@ -33,9 +33,9 @@ impl HipBackend {
         let mut world = std::ptr::null_mut();
         unsafe {
             ffi::phys_config_default(cfg.as_mut_ptr()); // reference constants: gravity (0,-9.81,0) at (0,0,1.5), CG 1000/1e-2/1e-3
-            // the frame loop renders on the same GPU (wgpu) while the next update may already run: with collisions on, say so
-            // (no effect on the reference path itself)
-            (*cfg.as_mut_ptr()).flags |= ffi::PHYS_FLAG_SHARED_GPU;
+            // the frame loop renders on the same GPU (wgpu) while the next update may already run: the default (guarded start of
+            // the contact solver's one big launch) is the right one; a headless batch run that has
+            // the GPU to itself may add ffi::PHYS_FLAG_EXCLUSIVE_GPU
             check(ffi::phys_create(cfg.as_ptr(), &mut world));
         }
         Self { world, uploaded_bodies: usize::MAX, uploaded_constraints: usize::MAX }

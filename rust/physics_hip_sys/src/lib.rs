@@ -18,6 +18,7 @@ pub const PHYS_FLAG_BROADPHASE_ONLY: u32 = 0x8;
 pub const PHYS_FLAG_SOLVER_PER_COLOR: u32 = 0x10;
 pub const PHYS_FLAG_SHARED_GPU: u32 = 0x20;
 pub const PHYS_FLAG_SOLVER_CLUSTER: u32 = 0x40;
+pub const PHYS_FLAG_EXCLUSIVE_GPU: u32 = 0x80;
 
 #[repr(C)]
 #[derive(Clone, Copy)]

@@ -466,15 +466,15 @@ def test_cluster_solver_bit_exact_against_the_oracle_on_a_33k_tower():
 
 
 def test_guarded_start_of_the_cluster_solver_changes_nothing():
-    """PHYS_FLAG_SHARED_GPU (implied by a second world on the device): every workgroup of the cluster solver's launch is
-    counted in before anything is written, and a launch that cannot be resident as a whole is called off and tried again
-    (other streams' kernels beside the start of a launch leave register holes that cost it workgroups: DESIGN.md). Same
-    bits with and without, and the cluster solver runs in both."""
+    """The default start of the cluster solver (also implied by a second world on the device): every workgroup of the launch
+    is counted in before anything is written, and a launch that cannot be resident as a whole is called off and tried again
+    (other streams' kernels beside the start of a launch leave register holes that cost it workgroups: DESIGN.md).
+    PHYS_FLAG_EXCLUSIVE_GPU skips the count. Same bits with and without, and the cluster solver runs in both."""
     import physics_amd
     from physics_amd import scenes
     sc = scenes.c5(16, 130, 16)
     states = []
-    for extra in (0, physics_amd.FLAG_SHARED_GPU):
+    for extra in (physics_amd.FLAG_EXCLUSIVE_GPU, 0):
         w = physics_amd.World(sc.config(flags=sc.flags | extra | physics_amd.FLAG_SOLVER_CLUSTER))
         sc.populate(w)
         w.update_n(DT, 8)
@@ -490,14 +490,14 @@ def test_guarded_start_of_the_cluster_solver_changes_nothing():
 
 
 def test_cluster_solver_under_a_stream_of_foreign_kernels():
-    """The case PHYS_FLAG_SHARED_GPU is for: bf16 GEMMs and small element-wise kernels are launched on another stream
+    """The case the guarded start (the default) is for: bf16 GEMMs and small element-wise kernels are launched on another stream
     right before every update of a 33k tower on the cluster solver, so that some of them run beside the START of its
     launch. No hand-off time-out, and the same bits as a world stepping on a quiet GPU."""
     import torch
     import physics_amd
     from physics_amd import scenes
     sc = scenes.c5(16, 130, 16)
-    busy = physics_amd.World(sc.config(flags=sc.flags | physics_amd.FLAG_SHARED_GPU | physics_amd.FLAG_SOLVER_CLUSTER))
+    busy = physics_amd.World(sc.config(flags=sc.flags | physics_amd.FLAG_SOLVER_CLUSTER))
     sc.populate(busy)
     side = torch.cuda.Stream()
     m = torch.randn(1024, 1024, device="cuda", dtype=torch.bfloat16)
