@@ -66,6 +66,9 @@ extern "C" {
                                             cluster, one launch) wherever the scene admits it (>= 32768 bodies, > 40k
                                             manifolds), instead of only where it is the fastest path (>= 200k manifolds).
                                             Bit-identical results; for tests and measurements */
+#define PHYS_FLAG_NO_WARM_START 0x100u   /* contact solver: start every update from zero impulses (rounds 1-2). Default: a manifold
+                                            that persists starts from the impulses it ended the previous update with
+                                            (include/spec/contact_solve.h: warm starting; one sweep more per update) */
 
 typedef struct phys_config {
     uint32_t abi_version;       /* PHYS_ABI_VERSION */

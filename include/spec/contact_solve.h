@@ -26,6 +26,16 @@
  *          colour not yet used at those bodies, and marks it used there.
  *   repeat until all are coloured. At most PHYS_MAX_COLORS colours.
  *
+ * Warm starting (what makes a stack stand): the accumulated impulses a manifold ends an update with are remembered
+ * with its contact points, and a manifold of the same pair in the next update starts from them - point k takes the
+ * impulses of the first remembered point within PHYS_WARM_DIST of it that no earlier point took (normal impulse when the
+ * normals agree to PHYS_WARM_DOT; friction impulses only when the tangent bases do too). The solve then has one sweep
+ * more, in front of the others: sweep 0 APPLIES the starting impulses of every manifold to its bodies, colour by colour
+ * in solve order (the same row_apply as a relaxation, no clamping, nothing changed in the rows); sweeps 1..iterations
+ * relax as before. Eight iterations never carried a tall tower from zero (rounds 1-2: the bottom layer of the 256k tower
+ * sank 0.12 in 40 updates and kept sinking); started from the previous update's answer they only have to follow.
+ * PHYS_FLAG_NO_WARM_START runs the solver cold (no sweep 0, rows start from zero: the behaviour of rounds 1-2).
+ *
  * Persistent colouring (what makes a steady scene cheap): a manifold (a, b) that also existed in the previous
  * update KEEPS its colour; the rounds above run over the NEW manifolds only, with `used` pre-seeded by the kept
  * colours. The colouring is thus a pure function of (previous colouring, manifold set). A new manifold takes the
@@ -41,6 +51,8 @@
 
 #define PHYS_MAX_COLORS 64
 #define PHYS_COLOR_CACHE_PERIOD 64
+#define PHYS_WARM_DIST 0.05f /* a remembered contact point within this distance (world units) is the same point */
+#define PHYS_WARM_DOT 0.999f /* cosine of the angle (2.5 degrees) within which two directions count as the same */
 
 typedef struct {
     float dt;
@@ -201,11 +213,54 @@ PHYS_HD void row_apply(float lambda, v3 lA, v3 lB, const jac_row_t* j, int has_b
     }
 }
 
+/* ---- warm starting: what is remembered of a manifold, and the impulses a new manifold of the same pair starts from */
+typedef struct {
+    v3 normal;
+    int count; /* 0: nothing remembered */
+    v3 pt[4];  /* world-space contact points of that update */
+    float pn[4], pt0[4], pt1[4]; /* accumulated impulses its solve ended with */
+} warm_t;
+
+PHYS_HD void warm_match(const manifold_t* m, const warm_t* w, float* pn, float* pt0, float* pt1) {
+    PHYS_UNROLL
+    for (int k = 0; k < 4; ++k) { pn[k] = 0.0f; pt0[k] = 0.0f; pt1[k] = 0.0f; }
+    if (w->count <= 0 || !(v3_dot(m->normal, w->normal) >= PHYS_WARM_DOT)) return;
+    /* friction impulses live in the tangent basis of their normal: carried over only if that basis is (nearly) the same */
+    v3 a1, a2, b1, b2;
+    tangent_basis(m->normal, &a1, &a2);
+    tangent_basis(w->normal, &b1, &b2);
+    const int same_basis = v3_dot(a1, b1) >= PHYS_WARM_DOT && v3_dot(a2, b2) >= PHYS_WARM_DOT;
+    int taken0 = 0, taken1 = 0, taken2 = 0, taken3 = 0; /* (flags, not a mask indexed at run time) */
+    PHYS_UNROLL
+    for (int k = 0; k < 4; ++k) {
+        if (k < m->count) {
+            int found = 0;
+            PHYS_UNROLL
+            for (int j = 0; j < 4; ++j) {
+                const int taken = j == 0 ? taken0 : (j == 1 ? taken1 : (j == 2 ? taken2 : taken3));
+                if (!found && j < w->count && !taken) {
+                    const v3 d = v3_sub(m->pt[k], w->pt[j]);
+                    if (v3_dot(d, d) <= PHYS_WARM_DIST * PHYS_WARM_DIST) {
+                        found = 1;
+                        if (j == 0) taken0 = 1; else if (j == 1) taken1 = 1; else if (j == 2) taken2 = 1; else taken3 = 1;
+                        pn[k] = w->pn[j];
+                        if (same_basis) { pt0[k] = w->pt0[j]; pt1[k] = w->pt1[j]; }
+                    }
+                }
+            }
+        }
+    }
+}
+
 /* one row: friction direction t (0, 1) or the normal (t = 2) of point k */
 PHYS_HD void solve_row_dir(solver_manifold_t* sm, int k, int t, const jac_row_t* j, v3 lA, v3 lB, float friction, v3* vA,
-                           v3* wA, v3* vB, v3* wB) {
+                           v3* wA, v3* vB, v3* wB, int apply_only) {
     contact_row_t* r = &sm->row[k];
     const int has_b = sm->has_b;
+    if (apply_only) { /* sweep 0 of a warm-started solve: the row's starting impulse reaches the bodies, nothing else moves */
+        row_apply(t == 0 ? r->pt[0] : (t == 1 ? r->pt[1] : r->pn), lA, lB, j, has_b, vA, wA, vB, wB);
+        return;
+    }
     if (t < 2) {
         const v3 dir = t == 0 ? sm->t1 : sm->t2;
         const float vt = row_velocity(dir, j, has_b, *vA, *wA, *vB, *wB);
@@ -229,19 +284,21 @@ PHYS_HD void solve_row_dir(solver_manifold_t* sm, int k, int t, const jac_row_t*
 
 /* one Gauss-Seidel sweep over the points of one manifold; velocities are updated in place. Two drivers of the
  * SAME arithmetic: with the Jacobians made beforehand (the sequential part is then as short as it gets) ... */
-PHYS_HD void solve_manifold(solver_manifold_t* sm, const solver_jac_t* J, float friction, v3* vA, v3* wA, v3* vB, v3* wB) {
+PHYS_HD void solve_manifold(solver_manifold_t* sm, const solver_jac_t* J, float friction, v3* vA, v3* wA, v3* vB, v3* wB,
+                            int apply_only) {
     PHYS_UNROLL
     for (int k = 0; k < 4; ++k) {
         if (k < sm->count) {
             PHYS_UNROLL
-            for (int t = 0; t < 3; ++t) solve_row_dir(sm, k, t, &J->j[k][t], J->lA[t], J->lB[t], friction, vA, wA, vB, wB);
+            for (int t = 0; t < 3; ++t)
+                solve_row_dir(sm, k, t, &J->j[k][t], J->lA[t], J->lB[t], friction, vA, wA, vB, wB, apply_only);
         }
     }
 }
 
 /* ... or made row by row on the way (one quarter of the registers; same values, same results) */
 PHYS_HD void solve_manifold_lazy(solver_manifold_t* sm, float friction, float invMA, const m33* IA, float invMB,
-                                 const m33* IB, v3* vA, v3* wA, v3* vB, v3* wB) {
+                                 const m33* IB, v3* vA, v3* wA, v3* vB, v3* wB, int apply_only) {
     const v3 zero = v3_make(0.0f, 0.0f, 0.0f);
     v3 lA[3], lB[3];
     PHYS_UNROLL
@@ -257,7 +314,7 @@ PHYS_HD void solve_manifold_lazy(solver_manifold_t* sm, float friction, float in
             for (int t = 0; t < 3; ++t) {
                 jac_row_t j;
                 jac_row_make(sm, k, t == 0 ? sm->t1 : (t == 1 ? sm->t2 : sm->n), IA, IB, &j);
-                solve_row_dir(sm, k, t, &j, lA[t], lB[t], friction, vA, wA, vB, wB);
+                solve_row_dir(sm, k, t, &j, lA[t], lB[t], friction, vA, wA, vB, wB, apply_only);
             }
         }
     }
@@ -279,8 +336,8 @@ typedef struct {
     float mass[4][3];            /* row masses of t1, t2, n per point */
 } geo_manifold_t;
 
-PHYS_HD void solve_manifold_geo(geo_manifold_t* gm, int make_masses, float friction, v3 xA, float invMA, const m33* IA, v3 xB,
-                                float invMB, const m33* IB, v3* vA, v3* wA, v3* vB, v3* wB) {
+PHYS_HD void solve_manifold_geo(geo_manifold_t* gm, int make_masses, int apply_only, float friction, v3 xA, float invMA, const m33* IA,
+                                v3 xB, float invMB, const m33* IB, v3* vA, v3* wA, v3* vB, v3* wB) {
     const v3 zero = v3_make(0.0f, 0.0f, 0.0f);
     const int has_b = gm->has_b;
     v3 lA[3], lB[3];
@@ -311,6 +368,10 @@ PHYS_HD void solve_manifold_geo(geo_manifold_t* gm, int make_masses, float frict
                     float km = invMA + v3_dot(j.mA, j.aA);
                     if (has_b) km = (km + invMB) + v3_dot(j.mB, j.aB);
                     gm->mass[k][t] = km > 0.0f ? 1.0f / km : 0.0f;
+                }
+                if (apply_only) {                                /* solve_row_dir, sweep 0 */
+                    row_apply(t == 0 ? gm->pt0[k] : (t == 1 ? gm->pt1[k] : gm->pn[k]), lA[t], lB[t], &j, has_b, vA, wA, vB, wB);
+                    continue;
                 }
                 const float mass = gm->mass[k][t];
                 const float vrel = row_velocity(dir, &j, has_b, *vA, *wA, *vB, *wB);

@@ -19,6 +19,7 @@ void CollisionWorld::configure(const phys_config& cfg) {
     sp.slop = cfg.slop;
     sp.friction = cfg.friction;
     sp.max_bias = cfg.max_bias;
+    warm_start = !(cfg.flags & PHYS_FLAG_NO_WARM_START);
 }
 
 static inline v3 V(const float* p) { return v3_make(p[0], p[1], p[2]); }
@@ -248,11 +249,21 @@ void CollisionWorld::solve(std::vector<RigidBody>& bodies, float dt) {
         solver_prep(&g, has_b, V(bodies[mf.a].position), has_b ? V(bodies[mf.b].position) : v3_make(0, 0, 0),
                     inv_mass[mf.a], &inv_inertia[mf.a], has_b ? inv_mass[mf.b] : 0.0f,
                     has_b ? &inv_inertia[mf.b] : &zero, &sp, &rows[m]);
+        if (warm_start) {  // a manifold of the same pair in the previous update: start from what its solve ended with
+            auto it = warm_cache.find(((uint64_t)mf.a << 32) | mf.b);
+            if (it != warm_cache.end()) {
+                float pn[4], pt0[4], pt1[4];
+                warm_match(&g, &it->second, pn, pt0, pt1);
+                for (int k = 0; k < 4; ++k) { rows[m].row[k].pn = pn[k]; rows[m].row[k].pt[0] = pt0[k]; rows[m].row[k].pt[1] = pt1[k]; }
+            }
+        }
     }
     // colour-major order; inside a colour the order is irrelevant (disjoint bodies)
     std::vector<std::vector<size_t>> by_color(n_colors);
     for (size_t m = 0; m < M; ++m) by_color[color[m]].push_back(m);
-    for (uint32_t it = 0; it < iterations; ++it)
+    // sweep 0 of a warm-started solve applies the starting impulses; sweeps 1..iterations relax (contact_solve.h)
+    const uint32_t first_sweep = warm_start ? 0u : 1u;
+    for (uint32_t it = first_sweep; it <= iterations; ++it)
         for (uint32_t c = 0; c < n_colors; ++c) {
             // the manifolds of one colour touch disjoint bodies: any order, any number of threads, same bits
             const std::vector<size_t>& cls = by_color[c];
@@ -266,7 +277,7 @@ void CollisionWorld::solve(std::vector<RigidBody>& bodies, float dt) {
                 v3 vB = v3_make(0, 0, 0), wB = v3_make(0, 0, 0);
                 if (has_b) { vB = V(bodies[mf.b].lin_velocity); wB = V(bodies[mf.b].angular_velocity); }
                 solve_manifold_lazy(&rows[m], sp.friction, inv_mass[mf.a], &inv_inertia[mf.a], has_b ? inv_mass[mf.b] : 0.0f,
-                                    has_b ? &inv_inertia[mf.b] : &zero, &vA, &wA, &vB, &wB);
+                                    has_b ? &inv_inertia[mf.b] : &zero, &vA, &wA, &vB, &wB, /*apply_only=*/it == 0u);
                 A.lin_velocity[0] = vA.x; A.lin_velocity[1] = vA.y; A.lin_velocity[2] = vA.z;
                 A.angular_velocity[0] = wA.x; A.angular_velocity[1] = wA.y; A.angular_velocity[2] = wA.z;
                 if (has_b) {
@@ -276,6 +287,24 @@ void CollisionWorld::solve(std::vector<RigidBody>& bodies, float dt) {
                 }
             }
         }
+    remember_impulses(rows);
+}
+
+// what the next update's manifolds of the same pairs start from
+void CollisionWorld::remember_impulses(const std::vector<solver_manifold_t>& rows) {
+    warm_cache.clear();
+    if (!warm_start) return;
+    warm_cache.reserve(2 * manifolds.size());
+    for (size_t m = 0; m < manifolds.size(); ++m) {
+        const Manifold& mf = manifolds[m];
+        warm_t w;
+        w.normal = mf.normal; w.count = mf.count;
+        for (int k = 0; k < 4; ++k) {
+            w.pt[k] = mf.pt[k];
+            w.pn[k] = rows[m].row[k].pn; w.pt0[k] = rows[m].row[k].pt[0]; w.pt1[k] = rows[m].row[k].pt[1];
+        }
+        warm_cache[((uint64_t)mf.a << 32) | mf.b] = w;
+    }
 }
 
 void CollisionWorld::collide_and_solve(std::vector<RigidBody>& bodies, float dt) {

@@ -49,8 +49,11 @@ struct CollisionWorld {
     void narrowphase(const std::vector<RigidBody>& bodies);
     void color_manifolds(size_t n_bodies, bool persistent);
     std::unordered_map<uint64_t, uint32_t> color_cache;  // (a << 32 | b) -> colour of the previous update
+    std::unordered_map<uint64_t, warm_t> warm_cache;     // (a << 32 | b) -> what the solve of the previous update ended with
+    bool warm_start = true;                              // contact_solve.h "warm starting" (off: PHYS_FLAG_NO_WARM_START)
     uint64_t color_epoch = 0;                            // updates since the bodies were set
     void solve(std::vector<RigidBody>& bodies, float dt);
+    void remember_impulses(const std::vector<solver_manifold_t>& rows);
     void collide_and_solve(std::vector<RigidBody>& bodies, float dt);
     std::vector<size_t> sorted_manifold_order() const;
 };

@@ -79,6 +79,7 @@ int32_t oracle_set_bodies(oracle_world* w, uint64_t n, const float* pos, const f
     }
     w->state.previous_solution.reset();
     w->col.color_cache.clear();
+    w->col.warm_cache.clear();
     w->col.color_epoch = 0;
     return PHYS_OK;
 }
@@ -368,9 +369,9 @@ int32_t oracle_solve_drivers_mismatch(const float* in, int32_t count, int32_t ha
     solver_jac_t J;
     solver_jacobians(&a, invMA, &IA, invMB, &IB, &J);
     for (int it = 0; it < iters; ++it) {
-        solve_manifold(&a, &J, friction, &va[0], &va[1], &va[2], &va[3]);
-        solve_manifold_lazy(&b, friction, invMA, &IA, invMB, &IB, &vb[0], &vb[1], &vb[2], &vb[3]);
-        solve_manifold_geo(&c, it == 0, friction, xA, invMA, &IA, xB, invMB, &IB, &vc[0], &vc[1], &vc[2], &vc[3]);
+        solve_manifold(&a, &J, friction, &va[0], &va[1], &va[2], &va[3], 0);
+        solve_manifold_lazy(&b, friction, invMA, &IA, invMB, &IB, &vb[0], &vb[1], &vb[2], &vb[3], 0);
+        solve_manifold_geo(&c, it == 0, 0, friction, xA, invMA, &IA, xB, invMB, &IB, &vc[0], &vc[1], &vc[2], &vc[3]);
     }
     int32_t bad = 0;
     for (int k = 0; k < 4; ++k) bad += std::memcmp(&va[k], &vb[k], sizeof(v3)) != 0;

@@ -22,6 +22,7 @@ FLAG_SOLVER_PER_COLOR = 16
 FLAG_SHARED_GPU = 32
 FLAG_SOLVER_CLUSTER = 64
 FLAG_EXCLUSIVE_GPU = 128
+FLAG_NO_WARM_START = 256
 GROUND_ID = 0xFFFFFFFF
 
 f32p = C.POINTER(C.c_float)

@@ -171,13 +171,13 @@ int32_t phys_destroy(phys_world* w) {
     if (w->stream) (void)hipStreamSynchronize(w->stream);
     DevBuf<float>* fb[] = {&w->pos, &w->rot, &w->vel, &w->force, &w->torque, &w->inv_inertia_diag,
                            &w->inv_inertia, &w->half_extent, &w->aabb, &w->cg_x, &w->cg_r, &w->cg_p, &w->cg_ap,
-                           &w->cg_rhs, &w->cg_c, &w->cg_scratch, &w->cg_jl, &w->geo, &w->man_geo, &w->row_n,
+                           &w->cg_rhs, &w->cg_c, &w->cg_scratch, &w->cg_jl, &w->geo, &w->man_geo_prev, &w->man_imp, &w->man_imp_prev, &w->man_geo, &w->row_n,
                            &w->row_pt, &w->row_tb, &w->row_acc, &w->row_all, &w->flow_vel, &w->sorted_box, &w->slot_box};
     for (auto* b : fb) b->free();
     DevBuf<uint32_t>* ub[] = {&w->shape, &w->global_id, &w->cg_status, &w->bucket_of, &w->bucket_count,
                               &w->bucket_start, &w->bucket_cursor, &w->sorted_ids, &w->slot_ids, &w->grid_ovf, &w->scan_block_sums, &w->pairs,
                               &w->man_a, &w->man_b, &w->man_color, &w->row_hdr, &w->halo_block_counts,
-                              &w->cluster_slot, &w->cluster_body, &w->body_shared, &w->active_flag, &w->active_rank, &w->seg_count, &w->seg_start, &w->man_rank,
+                              &w->man_prev, &w->cluster_slot, &w->cluster_body, &w->body_shared, &w->active_flag, &w->active_rank, &w->seg_count, &w->seg_start, &w->man_rank,
                               &w->row_src, &w->cross_pairs, &w->color_block_hist, &w->cg_cols};
     for (auto* b : ub) b->free();
     w->man_prio.free(); w->color_state.free(); w->bucket_count.free(); w->step_zero.free();

@@ -815,6 +815,13 @@ int32_t collision_alloc(phys_world* w) {
         PHYS_HIP_TRY(w->man_a.resize(M)); PHYS_HIP_TRY(w->man_b.resize(M));
         PHYS_HIP_TRY(w->man_color.resize(M));
         PHYS_HIP_TRY(w->man_geo.resize(32 * M));
+        w->warm = !(w->cfg.flags & PHYS_FLAG_NO_WARM_START) && M < (1ull << 26);  // the colour table's value word holds 26 bits of index
+        if (w->warm) {
+            PHYS_HIP_TRY(w->man_geo_prev.resize(32 * M));
+            PHYS_HIP_TRY(w->man_imp.resize(12 * M));
+            PHYS_HIP_TRY(w->man_imp_prev.resize(12 * M));
+            PHYS_HIP_TRY(w->man_prev.resize(M));
+        }
         PHYS_HIP_TRY(w->man_prio.resize(M));
         PHYS_HIP_TRY(w->row_src.resize(M));
         PHYS_HIP_TRY(w->unc_list.resize(2 * M));

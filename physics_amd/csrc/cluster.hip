@@ -356,7 +356,10 @@ __global__ __launch_bounds__(kClusterThreads, DIAG ? kClusterPerCuDiag : kCluste
                                                                   const uint32_t* __restrict__ body_shared,
                                                                   const uint32_t* __restrict__ seg_start, uint32_t slots,
                                                                   long long timeout_ticks, uint32_t ablate, uint32_t attempt,
-                                                                  uint32_t last_attempt, long long arrive_ticks) {
+                                                                  uint32_t last_attempt, long long arrive_ticks,
+                                                                  uint32_t warm_sweep /* sweep 0 applies the starting impulses (and
+                                                                  `iterations` counts it) */, const uint32_t* __restrict__ row_src,
+                                                                  float* __restrict__ man_imp /* 12 floats per manifold, or null */) {
     extern __shared__ __attribute__((aligned(16))) float4 s_lds[];  // [4 * slots]: {v, tag} {w, 1/m} {x} {I^-1 diag};  then the segment table
     float4* s_body = s_lds;
     uint32_t* s_seg = reinterpret_cast<uint32_t*>(s_lds + 4 * (size_t)slots);  // PHYS_MAX_COLORS + 1 row offsets
@@ -468,10 +471,10 @@ __global__ __launch_bounds__(kClusterThreads, DIAG ? kClusterPerCuDiag : kCluste
         for (int k = 0; k < 3; ++k) {
             acc[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             mas[k] = acc[k];
-            if (lit != 0u) {  // written by this very lane: the impulses one iteration ago, the masses in iteration 0
-                acc[k] = row[(kClusterPlaneAcc + k) * cap];
-                mas[k] = row[(kClusterPlaneMass + k) * cap];
-            }
+            // the impulses: written by this very lane one sweep ago - or, for sweep 0 of a warm-started solve, by
+            // k_rows_build (the starting impulses); the masses: by this lane in sweep 0
+            if (lit != 0u || warm_sweep != 0u) acc[k] = row[(kClusterPlaneAcc + k) * cap];
+            if (lit != 0u) mas[k] = row[(kClusterPlaneMass + k) * cap];
         }
     };
     hraw = make_float4(0.0f, 0.0f, 0.0f, 0.0f); nn = hraw; fb = hraw; fi = hraw;
@@ -606,7 +609,9 @@ __global__ __launch_bounds__(kClusterThreads, DIAG ? kClusterPerCuDiag : kCluste
                     ctr->debug[7] = (col & 0xFFu) | ((it & 0xFFu) << 8);
                 }
                 if (!dead) {
-                    if (!(ablate & 2u)) solve_manifold_geo(&gm, it == 0u || (ablate & 32u), friction, xA, ima, &IA, xB, imb, &IB, &vA, &wA, &vB, &wB);
+                    if (!(ablate & 2u))
+                        solve_manifold_geo(&gm, it == 0u || (ablate & 32u), (warm_sweep != 0u && it == 0u) ? 1 : 0, friction, xA, ima, &IA, xB, imb,
+                                           &IB, &vA, &wA, &vB, &wB);
                     // ---- write back
                     if (modeA == 0u || modeA == 1u) {
                         s_body[4 * slotA] = make_float4(vA.x, vA.y, vA.z, __uint_as_float(etag | (tA + 1u)));
@@ -623,6 +628,12 @@ __global__ __launch_bounds__(kClusterThreads, DIAG ? kClusterPerCuDiag : kCluste
                     if (modeB == 1u || modeB == 2u) {
                         if (finalB) { st3(vel + 8 * (size_t)h.y, 0, vB); st3(vel + 8 * (size_t)h.y + 4, 0, wB); }
                         else if (modeB == 2u || pubB) { st_gran(rv, h.y * 32u, vB, etag | (tB + 1u)); st_gran(rv, h.y * 32u + 16u, wB, etag | (tB + 1u)); }
+                    }
+                    if (last_it && man_imp) {  // the solve's last sweep: remembered for the next update (contact_solve.h)
+                        float4* o = reinterpret_cast<float4*>(man_imp) + 3 * (size_t)row_src[d_row];
+                        o[0] = make_float4(gm.pn[0], gm.pt0[0], gm.pt1[0], gm.pn[1]);
+                        o[1] = make_float4(gm.pt0[1], gm.pt1[1], gm.pn[2], gm.pt0[2]);
+                        o[2] = make_float4(gm.pt1[2], gm.pn[3], gm.pt0[3], gm.pt1[3]);
                     }
                     if (!last_it) {  // impulses of points beyond the count are whatever came in: never used
                         float4* out = rows.all + d_row;
@@ -669,6 +680,8 @@ __global__ __launch_bounds__(kClusterThreads, DIAG ? kClusterPerCuDiag : kCluste
 
 void launch_solve_cluster(phys_world* w, void* row_all, uint64_t cap, float friction, const float* inertia, uint32_t stride,
                           bool diag, long long timeout_ticks) {
+    const uint32_t warm_sweep = w->warm ? 1u : 0u;
+    const uint32_t sweeps = w->cfg.solver_iterations + warm_sweep;
     static const uint32_t ablate = getenv("PHYS_DEBUG_ABLATE") ? (uint32_t)atoi(getenv("PHYS_DEBUG_ABLATE")) : 0u;
     ClusterRowArrays rows;
     rows.all = (float4*)row_all; rows.cap = cap;
@@ -710,9 +723,10 @@ void launch_solve_cluster(phys_world* w, void* row_all, uint64_t cap, float fric
         const uint32_t last = attempt + 1 == kAttempts ? 1u : 0u;
         // 100 MHz ticks: 0.5 ms, then 20 ms for the workgroups to come in (alone on the device they need ~10 us); < 0: no count
         const long long arrive_ticks = !guarded ? -1ll : (attempt == 0 ? 50000ll : 2000000ll);
-#define PHYS_CLUSTER_ARGS g, b, lds, w->stream, w->counters.p, w->cfg.solver_iterations, w->flow_epoch, rows, friction, inertia, stride, \
+#define PHYS_CLUSTER_ARGS g, b, lds, w->stream, w->counters.p, sweeps, w->flow_epoch, rows, friction, inertia, stride, \
                           w->vel.p, w->pos.p, w->flow_vel.p, (uint32_t)w->n, w->cluster_body.p, w->body_shared.p, w->seg_start.p,     \
-                          w->cluster_slots, timeout_ticks, ablate, attempt, last, arrive_ticks
+                          w->cluster_slots, timeout_ticks, ablate, attempt, last, arrive_ticks, warm_sweep, w->row_src.p,              \
+                          w->warm ? w->man_imp.p : (float*)nullptr
         if (guarded) {
             if (diag) hipLaunchKernelGGL((k_solve_cluster<true, true>), PHYS_CLUSTER_ARGS);
             else hipLaunchKernelGGL((k_solve_cluster<false, true>), PHYS_CLUSTER_ARGS);

@@ -67,7 +67,8 @@ __device__ __forceinline__ m33 ld_inertia_c(const float* __restrict__ p, uint32_
 }
 
 // Persistent colouring: ONE hash table (a << 32 | b) -> {colour, update stamp} that lives across updates. Open addressing,
-// linear probing, 16-byte entries {key, stamp << 32 | colour}; at least 1.5 slots per manifold SLOT of the world.
+// linear probing, 16-byte entries {key, stamp << 32 | manifold index << 6 | colour} (the index of the pair's manifold in
+// the update that stamped the entry: what the next update warm-starts from); at least 1.5 slots per manifold SLOT.
 //   * the narrow phase of update E looks every manifold up: an exact key match whose stamp is E - 1 ("was there in the
 //     previous update") keeps its colour and is re-stamped E on the spot - one 8-byte store to the line the probe has
 //     just read. Entries that are not re-stamped are dead from then on.
@@ -95,7 +96,7 @@ struct ColorTableJob {
 
 __device__ __forceinline__ void color_table_insert(const ColorTableJob& job, uint32_t a, uint32_t b, uint32_t m, StepCounters* ctr) {
     const unsigned long long key = ((unsigned long long)a << 32) | b;
-    const unsigned long long val = ((unsigned long long)job.stamp << 32) | job.man_color[m];
+    const unsigned long long val = ((unsigned long long)job.stamp << 32) | ((unsigned long long)(m & 0x3FFFFFFu) << 6) | (job.man_color[m] & 63u);
     uint32_t h = (uint32_t)(job.man_prio[m] >> 20) & job.mask;
     // bounded (see the walk in k_narrowphase); a manifold that finds no slot would be coloured afresh next time where the
     // oracle keeps its colour: the update is flagged (bit 6), never a silent divergence

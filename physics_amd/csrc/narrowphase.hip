@@ -13,6 +13,7 @@
 // Algorithmic bytes: per pair 8 + 2 x 44 (pos 12, rot 16, half 12, shape 4) = 96 B read;
 //   per manifold 100 B written (ids 8, count 4, normal 12, points 64, priority 8, colour 4).
 #include <cstdlib>
+#include <utility>
 
 #include "kernels.hpp"
 
@@ -45,6 +46,8 @@ __global__ __launch_bounds__(kNpThreads) void k_narrowphase(
     uint32_t cache_mask /* 0 = keep nothing this update */, uint32_t early_probe /* ask for the table entry before the shapes
     are tested */, uint32_t stamp /* of this update */,
     uint32_t* __restrict__ unc_list /* ids of the manifolds that did not keep a colour: round 0 of the colouring */,
+    uint32_t* __restrict__ man_prev /* warm starting: index of the pair's manifold in the previous update (null: off) */,
+    float* __restrict__ man_imp /* ... and this update's impulse records, zeroed here (a solve that never runs leaves zeros) */,
     StepCounters* __restrict__ ctr) {
     // per-wave totals of a trip, in two sets used alternately: a wave may start the next trip (and post its totals) while
     // another still reads this trip's to place its manifolds - there is no barrier at the end of a trip any more
@@ -114,7 +117,7 @@ __global__ __launch_bounds__(kNpThreads) void k_narrowphase(
         // A manifold that turns out to be beyond the capacity has then left its marks too: that update is flagged, its
         // solve skipped and its new manifolds never reach the table, so nothing of it survives.
         unsigned long long prio = 0ull, seen_a = 0ull, seen_b = 0ull, bit = 0ull;
-        uint32_t col = kUncolored;
+        uint32_t col = kUncolored, prev_m = 0xFFFFFFFFu, kept_h = 0;
         bool uncolored = false;
         if (has) {
             prio = color_priority(a, b);
@@ -131,8 +134,9 @@ __global__ __launch_bounds__(kNpThreads) void k_narrowphase(
                     have_early = false;
                     if (e.x == key) {
                         if ((uint32_t)(e.y >> 32) + 1u == stamp) {
-                            col = (uint32_t)e.y;
-                            cache[h].y = ((unsigned long long)stamp << 32) | col;
+                            col = (uint32_t)e.y & 63u;
+                            prev_m = ((uint32_t)e.y >> 6);  // the pair's manifold of the previous update
+                            kept_h = h;                     // re-stamped below, once this update's slot is known
                         }
                         ended = true;
                         break;  // a dead entry of this key: no live one follows
@@ -199,6 +203,13 @@ __global__ __launch_bounds__(kNpThreads) void k_narrowphase(
                 man_b[slot] = b;
                 man_prio[slot] = prio;
                 man_color[slot] = col;
+                // a kept entry is re-stamped with this update's manifold index (one 8-byte store to the line the probe read)
+                if (col != kUncolored) cache[kept_h].y = ((unsigned long long)stamp << 32) | ((unsigned long long)((uint32_t)slot & 0x3FFFFFFu) << 6) | col;
+                if (man_prev) {
+                    man_prev[slot] = prev_m;
+                    float4* imp = reinterpret_cast<float4*>(man_imp) + 3 * slot;
+                    imp[0] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); imp[1] = imp[0]; imp[2] = imp[0];
+                }
                 // (Measured and dropped: staging the records of a wave in LDS and copying them out as whole 128-byte lines -
                 // 4.5 write requests per manifold become 2 - left the kernel at 0.52 ms on C5: it waits on its chain of
                 // dependent round trips, not on the write path.)
@@ -736,6 +747,10 @@ void launch_narrowphase(phys_world* w) {
     static const char* probe_env = getenv("PHYS_DEBUG_NP_EARLY_PROBE");  // 0 / 1 forces it (measurements; same bits)
     const uint32_t early_probe = probe_env ? (uint32_t)(probe_env[0] == '1')
                                            : (uint32_t)(!w->hint.valid || 2ull * w->hint.n_manifolds >= (uint64_t)w->hint.n_pairs);
+    if (w->warm) {  // last update's records become "previous": what this update's kept manifolds start from
+        std::swap(w->man_geo.p, w->man_geo_prev.p);
+        std::swap(w->man_imp.p, w->man_imp_prev.p);
+    }
     PHYS_PROF(w, PHYS_STAGE_NARROW);
 #define PHYS_NP_LAUNCH(T)                                                                                              \
     do {                                                                                                               \
@@ -746,7 +761,7 @@ void launch_narrowphase(phys_world* w) {
                            w->cfg.ground_height, w->max_manifolds, w->man_a.p, w->man_b.p,                             \
                            w->man_color.p, w->man_geo.p, w->man_prio.p, w->color_state.p,                              \
                            w->color_state.p + n, reinterpret_cast<ulonglong2*>(w->ctab.p), cache_mask, early_probe, stamp, \
-                           w->unc_list.p, w->counters.p);                                                              \
+                           w->unc_list.p, w->warm ? w->man_prev.p : nullptr, w->man_imp.p, w->counters.p);             \
     } while (0)
     static const int np_threads_env = getenv("PHYS_DEBUG_NP_THREADS") ? atoi(getenv("PHYS_DEBUG_NP_THREADS")) : 0;  // measurements
     // 128 threads only while the whole stage is a few workgroups (C2: 10k manifolds); measured at 230k manifolds (C3):

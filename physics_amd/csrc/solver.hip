@@ -49,6 +49,21 @@ __device__ __forceinline__ m33 ld_inertia<true>(const float* __restrict__ p, uin
     return M;
 }
 
+// warm starting (contact_solve.h): where the impulses a solve ends with go, and where a row's starting impulses come from
+struct WarmJob {
+    const uint32_t* man_prev;  // null: warm starting is off (rows start from zero, no sweep 0)
+    const float* geo_prev;     // 128-byte manifold records of the previous update
+    const float* imp_prev;     // 12 floats per manifold: what its solve ended with
+    float* imp;                // this update's (written by the last sweep of whichever solver kernel runs)
+    const uint32_t* row_src;   // row -> manifold
+};
+__device__ __forceinline__ void store_final_impulses(const WarmJob& wj, uint32_t d, const float pn[4], const float pt0[4], const float pt1[4]) {
+    float4* o = reinterpret_cast<float4*>(wj.imp) + 3 * (size_t)wj.row_src[d];
+    o[0] = make_float4(pn[0], pt0[0], pt1[0], pn[1]);
+    o[1] = make_float4(pt0[1], pt1[1], pn[2], pt0[2]);
+    o[2] = make_float4(pt1[2], pn[3], pt0[3], pt1[3]);
+}
+
 struct RowArrays {
     float4* all;  // the 16 planes in one piece: plane p of row d = all[p * cap + d] (0 hdr, 1 n, 2-3 tb, 4-11 pt, 12-15 acc)
     uint4* hdr;
@@ -71,7 +86,8 @@ __global__ __launch_bounds__(256) void k_rows_build(StepCounters* __restrict__ c
                                                     int flow /* 1: k_solve_flow runs this step (tickets, no zeroed impulses) */,
                                                     ColorTableJob table, const uint32_t* __restrict__ cluster_slot,
                                                     const uint32_t* __restrict__ body_shared,
-                                                    uint32_t cluster_slots /* 0: not a cluster-solver step */, uint32_t cluster_count) {
+                                                    uint32_t cluster_slots /* 0: not a cluster-solver step */, uint32_t cluster_count,
+                                                    WarmJob warm) {
     if (ctr->overflow) return;  // never solve a truncated set; phys_sync / phys_get_stats report it
     const uint32_t M = ctr->n_manifolds;
     const uint64_t cap = rows.cap;
@@ -90,6 +106,26 @@ __global__ __launch_bounds__(256) void k_rows_build(StepCounters* __restrict__ c
             g.depth[k] = p.w;
         }
         const int has_b = b != PHYS_GROUND_ID;
+        // warm starting: the impulses this row starts from = what the same pair's manifold of the previous update ended
+        // with, matched point by point (contact_solve.h warm_match); zero for a new pair or with warm starting off
+        float w_pn[4] = {0.0f, 0.0f, 0.0f, 0.0f}, w_pt0[4] = {0.0f, 0.0f, 0.0f, 0.0f}, w_pt1[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (warm.man_prev) {
+            const uint32_t pm = warm.man_prev[m];
+            if (pm != 0xFFFFFFFFu) {
+                const float4* prec = reinterpret_cast<const float4*>(warm.geo_prev) + 8 * (size_t)pm;
+                const float4* pimp = reinterpret_cast<const float4*>(warm.imp_prev) + 3 * (size_t)pm;
+                const float4 q0 = prec[0], q1 = prec[1], i0 = pimp[0], i1 = pimp[1], i2 = pimp[2];
+                warm_t wt;
+                wt.count = (int)__float_as_uint(q0.z);
+                wt.normal = v3_make(q1.x, q1.y, q1.z);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { const float4 p = prec[2 + k]; wt.pt[k] = v3_make(p.x, p.y, p.z); }
+                wt.pn[0] = i0.x; wt.pt0[0] = i0.y; wt.pt1[0] = i0.z; wt.pn[1] = i0.w;
+                wt.pt0[1] = i1.x; wt.pt1[1] = i1.y; wt.pn[2] = i1.z; wt.pt0[2] = i1.w;
+                wt.pt1[2] = i2.x; wt.pn[3] = i2.y; wt.pt0[3] = i2.z; wt.pt1[3] = i2.w;
+                warm_match(&g, &wt, w_pn, w_pt0, w_pt1);
+            }
+        }
         // persistent colouring: a manifold that is new in this update enters the colour table (kernels.hpp)
         if (table.tab && (table.all || __float_as_uint(r0.w) == 0u)) color_table_insert(table, a, b, m, ctr);
         uint32_t ticket = 0;
@@ -142,6 +178,11 @@ __global__ __launch_bounds__(256) void k_rows_build(StepCounters* __restrict__ c
             for (int k = 0; k < 4; ++k)
                 if (k < g.count)
                     rows.all[(size_t)(2 + k) * cap + d] = make_float4(g.pt[k].x, g.pt[k].y, g.pt[k].z, contact_bias(g.depth[k], &sp));
+            if (warm.man_prev) {  // the starting impulses, packed like the solver packs them (planes 6-8; read in sweep 0)
+                rows.all[(size_t)6 * cap + d] = make_float4(w_pn[0], w_pt0[0], w_pt1[0], w_pn[1]);
+                rows.all[(size_t)7 * cap + d] = make_float4(w_pt0[1], w_pt1[1], w_pn[2], w_pt0[2]);
+                rows.all[(size_t)8 * cap + d] = make_float4(w_pt1[2], w_pn[3], w_pt0[3], w_pt1[3]);
+            }
             if (((info >> 30) & 3u) == 2u) {
                 // body B belongs to another cluster: what does not change during the solve rides with the row (planes 12,
                 // 13), or fetching it by body id would be a second dependent round trip in every colour step of the solver
@@ -174,7 +215,9 @@ __global__ __launch_bounds__(256) void k_rows_build(StepCounters* __restrict__ c
                 const contact_row_t& c = sm.row[k];
                 rows.pt[(size_t)(2 * k) * cap + d] = make_float4(c.rA.x, c.rA.y, c.rA.z, c.normal_mass);
                 rows.pt[(size_t)(2 * k + 1) * cap + d] = make_float4(c.rB.x, c.rB.y, c.rB.z, c.tangent_mass[0]);
-                if (!flow) rows.acc[(size_t)k * cap + d] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                // accumulated impulses of point k: zero, or where the previous update left off. (The dataflow kernels read
+                // these with plain loads in their first sweep only when warm starting is on; tag 0 = no epoch ever.)
+                if (!flow || warm.man_prev) rows.acc[(size_t)k * cap + d] = make_float4(w_pn[k], w_pt0[k], w_pt1[k], 0.0f);
             }
         }
         rows.tb[d] = make_float4(sm.row[0].tangent_mass[1], sm.row[0].bias, sm.row[1].tangent_mass[1], sm.row[1].bias);
@@ -248,7 +291,9 @@ template <bool DIAG, bool EAGER = false>
 __device__ __forceinline__ void solve_row(uint32_t d, const RowArrays& rows, float friction,
                                           const float* __restrict__ inv_inertia,
                                           uint32_t inertia_stride /* 0: one tensor shared by every body */,
-                                          float* __restrict__ vel, uint32_t ablate = 0, uint32_t n_bodies = 1) {
+                                          float* __restrict__ vel, int apply_only /* sweep 0 of a warm-started solve */,
+                                          int last /* the solve's last sweep: the impulses are remembered */, const WarmJob& wj,
+                                          uint32_t ablate = 0, uint32_t n_bodies = 1) {
     RowRegs R;
     load_row<true, EAGER>(R, d, rows);
     solver_manifold_t& sm = R.sm;
@@ -268,16 +313,24 @@ __device__ __forceinline__ void solve_row(uint32_t d, const RowArrays& rows, flo
     if (sm.has_b) { IB = ld_inertia<DIAG>(inv_inertia, b * inertia_stride); B = ld_vel(vel, b); imb = B.inv_mass; vB = B.v; wB = B.w; }
     // rows made on the way: these kernels are throughput-bound and want the registers (k_solve_flow makes them all
     // beforehand, while it waits; same arithmetic)
-    if (!(ablate & 2u)) solve_manifold_lazy(&sm, friction, ima, &IA, imb, &IB, &vA, &wA, &vB, &wB);
+    if (!(ablate & 2u)) solve_manifold_lazy(&sm, friction, ima, &IA, imb, &IB, &vA, &wA, &vB, &wB, apply_only);
     A.v = vA; A.w = wA;
     if (!(ablate & 4u)) {
         st_vel(vel, a, A);
         if (sm.has_b) { B.v = vB; B.w = wB; st_vel(vel, b, B); }
     }
+    if (!apply_only) {  // (sweep 0 changes no impulse)
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
-        if (k < sm.count)
-            rows.acc[(size_t)k * rows.cap + d] = make_float4(sm.row[k].pn, sm.row[k].pt[0], sm.row[k].pt[1], 0.0f);
+        for (int k = 0; k < 4; ++k)
+            if (k < sm.count)
+                rows.acc[(size_t)k * rows.cap + d] = make_float4(sm.row[k].pn, sm.row[k].pt[0], sm.row[k].pt[1], 0.0f);
+    }
+    if (last && wj.man_prev) {
+        const float pn[4] = {sm.row[0].pn, sm.row[1].pn, sm.row[2].pn, sm.row[3].pn};
+        const float p0[4] = {sm.row[0].pt[0], sm.row[1].pt[0], sm.row[2].pt[0], sm.row[3].pt[0]};
+        const float p1[4] = {sm.row[0].pt[1], sm.row[1].pt[1], sm.row[2].pt[1], sm.row[3].pt[1]};
+        store_final_impulses(wj, d, pn, p0, p1);
+    }
 }
 
 // Tiles of `tile_rows` consecutive items handed to the workgroups of a launch so that the workgroups sharing an XCD
@@ -307,7 +360,7 @@ template <bool DIAG>
 __global__ __launch_bounds__(256) void k_solve_color(const StepCounters* __restrict__ ctr, uint32_t col, RowArrays rows,
                                                      float friction, const float* __restrict__ inv_inertia,
                                                      uint32_t inertia_stride, float* __restrict__ vel, uint32_t ablate,
-                                                     uint32_t n_bodies) {
+                                                     uint32_t n_bodies, int apply_only, int last, WarmJob wj) {
     if (ctr->overflow) return;
     const uint32_t start = ctr->color_start[col], end = ctr->color_start[col + 1];
     // XCD-aware tiles: the rows of a colour are in emission (= spatial) order, so a contiguous range of them touches a
@@ -317,7 +370,7 @@ __global__ __launch_bounds__(256) void k_solve_color(const StepCounters* __restr
     // 5.6 MB of gathered records when tiles were dealt in plain blockIdx order). Speed only: any mapping is correct.
     for (XcdTiles t(end - start, blockDim.x); t.valid(); t.next()) {
         const uint32_t d = start + t.tile * blockDim.x + threadIdx.x;
-        if (d < end) solve_row<DIAG, true>(d, rows, friction, inv_inertia, inertia_stride, vel, ablate, n_bodies);
+        if (d < end) solve_row<DIAG, true>(d, rows, friction, inv_inertia, inertia_stride, vel, apply_only, last, wj, ablate, n_bodies);
     }
 }
 
@@ -330,7 +383,8 @@ constexpr int kTailThreads = 512;  // 2 waves per SIMD: the row solve needs >128
 template <bool DIAG>
 __global__ __launch_bounds__(kTailThreads) void k_solve_tail(const StepCounters* __restrict__ ctr, uint32_t first, RowArrays rows,
                                                             float friction, const float* __restrict__ inv_inertia,
-                                                            uint32_t inertia_stride, float* __restrict__ vel) {
+                                                            uint32_t inertia_stride, float* __restrict__ vel, int apply_only,
+                                                            int last_sweep, WarmJob wj) {
     if (ctr->overflow) return;
     const uint32_t last = ctr->n_colors;
     if (first >= last) return;
@@ -342,7 +396,7 @@ __global__ __launch_bounds__(kTailThreads) void k_solve_tail(const StepCounters*
     for (uint32_t col = first; col < last; ++col) {
         const uint32_t start = s_start[col], end = s_start[col + 1];
         for (uint32_t d = start + threadIdx.x; d < end; d += kTailThreads)
-            solve_row<DIAG>(d, rows, friction, inv_inertia, inertia_stride, vel);
+            solve_row<DIAG>(d, rows, friction, inv_inertia, inertia_stride, vel, apply_only, last_sweep, wj);
         __threadfence_block();
         __syncthreads();
     }
@@ -405,7 +459,8 @@ __global__ __launch_bounds__(256) void k_solve_flow(StepCounters* __restrict__ c
                                                     RowArrays rows, float friction,
                                                     const float* __restrict__ inv_inertia, uint32_t inertia_stride,
                                                     float* vel, float* flow_vel, uint32_t n_bodies, long long timeout_ticks,
-                                                    uint32_t pipeline) {
+                                                    uint32_t pipeline, uint32_t warm_sweep /* sweep 0 applies the starting impulses;
+                                                    `iterations` counts it */, WarmJob wj) {
     __shared__ uint32_t s_item;
     if (ctr->overflow) return;
     const uint32_t M = ctr->n_manifolds;
@@ -508,6 +563,14 @@ __global__ __launch_bounds__(256) void k_solve_flow(StepCounters* __restrict__ c
                 }
             }
         }
+        const bool apply_only = warm_sweep != 0u && it == 0u;
+        if (apply_only && !done) {  // the starting impulses k_rows_build left in the impulse planes (plain loads: an earlier kernel wrote them)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) if (k < R.sm.count) {
+                const float4 a0 = rows.acc[(size_t)k * cap + d];
+                R.sm.row[k].pn = a0.x; R.sm.row[k].pt[0] = a0.y; R.sm.row[k].pt[1] = a0.z;
+            }
+        }
         const uint32_t rankA = R.ticket & 0xFFu, degA = (R.ticket >> 8) & 0xFFu;
         const uint32_t rankB = (R.ticket >> 16) & 0xFFu, degB = R.ticket >> 24;
         const uint32_t tA = done ? 0u : it * degA + rankA, tB = (done || !R.sm.has_b) ? 0u : it * degB + rankB;
@@ -567,7 +630,7 @@ __global__ __launch_bounds__(256) void k_solve_flow(StepCounters* __restrict__ c
                     }
                 }
                 if (!needA && !needB && !needAcc) {
-                    solve_manifold(&R.sm, &J, friction, &vA, &wA, &vB, &wB);
+                    solve_manifold(&R.sm, &J, friction, &vA, &wA, &vB, &wB, apply_only ? 1 : 0);
                     // publish: bodies first (they are what other rows wait for)
                     if (finalA) { BodyVel o; o.v = vA; o.inv_mass = ima; o.w = wA; o.mass = massA; st_vel(vel, R.a, o); }
                     else { st_granule(rv, R.a * 32u, vA, etag | (tA + 1u)); st_granule(rv, R.a * 32u + 16u, wA, etag | (tA + 1u)); }
@@ -580,6 +643,11 @@ __global__ __launch_bounds__(256) void k_solve_flow(StepCounters* __restrict__ c
                         for (int k = 0; k < 4; ++k) if (k < R.sm.count)
                             st_granule(ra, (k * cap + d) * 16u, v3_make(R.sm.row[k].pn, R.sm.row[k].pt[0], R.sm.row[k].pt[1]),
                                        etag | (it + 1u));
+                    } else if (wj.man_prev) {  // the solve's last sweep: remembered for the next update
+                        const float fpn[4] = {R.sm.row[0].pn, R.sm.row[1].pn, R.sm.row[2].pn, R.sm.row[3].pn};
+                        const float fp0[4] = {R.sm.row[0].pt[0], R.sm.row[1].pt[0], R.sm.row[2].pt[0], R.sm.row[3].pt[0]};
+                        const float fp1[4] = {R.sm.row[0].pt[1], R.sm.row[1].pt[1], R.sm.row[2].pt[1], R.sm.row[3].pt[1]};
+                        store_final_impulses(wj, d, fpn, fp0, fp1);
                     }
                     done = true;
                 }
@@ -631,7 +699,8 @@ template <bool DIAG>
 __global__ __launch_bounds__(256) void k_solve_flow_quad(StepCounters* __restrict__ ctr, uint32_t iterations, uint32_t epoch,
                                                          RowArrays rows, float friction,
                                                          const float* __restrict__ inv_inertia, uint32_t inertia_stride,
-                                                         float* vel, float* flow_vel, uint32_t n_bodies, long long timeout_ticks) {
+                                                         float* vel, float* flow_vel, uint32_t n_bodies, long long timeout_ticks,
+                                                         uint32_t warm_sweep, WarmJob wj) {
     __shared__ uint32_t s_item;
     if (ctr->overflow) return;
     const uint32_t M = ctr->n_manifolds;
@@ -724,9 +793,14 @@ __global__ __launch_bounds__(256) void k_solve_flow_quad(StepCounters* __restric
             }
             if (!has_body) x = zero;
         }
+        const bool apply_only = warm_sweep != 0u && it == 0u;
         bool need = !done && has_body && ticket != 0;
         bool need_acc = !done && it != 0 && q < count;  // lane q fetches the impulses of contact point q
         v3 my_acc = zero;
+        if (apply_only && !done && q < count) {  // the starting impulses of point q (plain load: k_rows_build wrote them)
+            const float4 a0 = rows.acc[(size_t)q * cap + d];
+            my_acc = v3_make(a0.x, a0.y, a0.z);
+        }
         uint32_t sweeps = 0;
         for (;;) {
             uint32_t gap = 0;
@@ -752,7 +826,7 @@ __global__ __launch_bounds__(256) void k_solve_flow_quad(StepCounters* __restric
             ready &= quad_perm_i<kQuadXor1>(ready);
             ready &= quad_perm_i<kQuadXor2>(ready);
             if (!done && ready) {
-                if (it != 0) {  // everybody needs every point's accumulated impulses
+                if (it != 0 || apply_only) {  // everybody needs every point's accumulated impulses
                     pn[0] = quad_perm<0x00>(my_acc.x); pt0[0] = quad_perm<0x00>(my_acc.y); pt1[0] = quad_perm<0x00>(my_acc.z);
                     pn[1] = quad_perm<0x55>(my_acc.x); pt0[1] = quad_perm<0x55>(my_acc.y); pt1[1] = quad_perm<0x55>(my_acc.z);
                     pn[2] = quad_perm<0xAA>(my_acc.x); pt0[2] = quad_perm<0xAA>(my_acc.y); pt1[2] = quad_perm<0xAA>(my_acc.z);
@@ -764,11 +838,16 @@ __global__ __launch_bounds__(256) void k_solve_flow_quad(StepCounters* __restric
 #pragma unroll
                         for (int t = 0; t < 3; ++t) {
                             // row_velocity: (dir.vB + aB.wB) - (dir.vA + aA.wA), the two sums made inside each pair
+                            float lambda;
+                            if (apply_only) {  // sweep 0 of a warm-started solve: the starting impulse reaches this lane's vector
+                                lambda = t == 0 ? pt0[k] : (t == 1 ? pt1[k] : pn[k]);
+                                x = v3_add(x, v3_scale(Rs[k][t], lambda));
+                                continue;
+                            }
                             const float part = v3_dot(Jv[k][t], x);
                             const float mine = part + quad_perm<kQuadXor1>(part);
                             const float other = quad_perm<kQuadXor2>(mine);
                             const float vrel = side_a ? other - mine : mine - other;
-                            float lambda;
                             if (t < 2) {  // solve_row_dir, friction
                                 const float mass = t == 0 ? tm0[k] : tm1[k];
                                 float& acc = t == 0 ? pt0[k] : pt1[k];
@@ -800,6 +879,12 @@ __global__ __launch_bounds__(256) void k_solve_flow_quad(StepCounters* __restric
                                   : q == 1 ? v3_make(pn[1], pt0[1], pt1[1])
                                   : q == 2 ? v3_make(pn[2], pt0[2], pt1[2]) : v3_make(pn[3], pt0[3], pt1[3]);
                     st_granule(ra, (q * cap + d) * 16u, mine, etag | (it + 1u));
+                }
+                if (last_it && wj.man_prev) {  // lane q remembers point q's impulses (zeros beyond the count)
+                    const v3 fin = q == 0 ? v3_make(pn[0], pt0[0], pt1[0])
+                                 : q == 1 ? v3_make(pn[1], pt0[1], pt1[1])
+                                 : q == 2 ? v3_make(pn[2], pt0[2], pt1[2]) : v3_make(pn[3], pt0[3], pt1[3]);
+                    st3(wj.imp + 12 * (size_t)wj.row_src[d] + 3u * q, 0, fin);
                 }
                 done = true;
             }
@@ -836,7 +921,8 @@ constexpr int kQuadRowsPerGroup = 64;
 template <bool DIAG>
 __global__ __launch_bounds__(256) void k_solve_color_quad(StepCounters* ctr, uint32_t col, RowArrays rows,
                                                           float friction, const float* __restrict__ inv_inertia,
-                                                          uint32_t inertia_stride, float* __restrict__ vel, uint32_t n_bodies) {
+                                                          uint32_t inertia_stride, float* __restrict__ vel, uint32_t n_bodies,
+                                                          int apply_only, int last, WarmJob wj) {
     __shared__ float4 s_rows[16][kQuadRowsPerGroup];  // [plane][row of this workgroup]
     if (ctr->overflow) return;
     const uint32_t start = ctr->color_start[col], end = ctr->color_start[col + 1];
@@ -941,11 +1027,16 @@ __global__ __launch_bounds__(256) void k_solve_color_quad(StepCounters* ctr, uin
 #pragma unroll
                 for (int t = 0; t < 3; ++t) {
                     // row_velocity: (dir.vB + aB.wB) - (dir.vA + aA.wA), the two sums made inside each pair
+                    float lambda;
+                    if (apply_only) {  // sweep 0 of a warm-started solve: the starting impulse reaches this lane's vector
+                        lambda = t == 0 ? pt0[k] : (t == 1 ? pt1[k] : pn[k]);
+                        x = v3_add(x, v3_scale(Rs[k][t], lambda));
+                        continue;
+                    }
                     const float part = v3_dot(Jv[k][t], x);
                     const float mine = part + quad_perm<kQuadXor1>(part);
                     const float other = quad_perm<kQuadXor2>(mine);
                     const float vrel = side_a ? other - mine : mine - other;
-                    float lambda;
                     if (t < 2) {  // solve_row_dir, friction
                         const float mass = t == 0 ? tm0[k] : tm1[k];
                         float& acc = t == 0 ? pt0[k] : pt1[k];
@@ -974,6 +1065,11 @@ __global__ __launch_bounds__(256) void k_solve_color_quad(StepCounters* ctr, uin
                                   : q == 1 ? make_float4(pn[1], pt0[1], pt1[1], 0.0f)
                                   : q == 2 ? make_float4(pn[2], pt0[2], pt1[2], 0.0f) : make_float4(pn[3], pt0[3], pt1[3], 0.0f);
                 rows.acc[(size_t)q * cap + d] = mine;
+            }
+            if (last && wj.man_prev) {  // lane q remembers point q's impulses (zeros beyond the count)
+                float* o = wj.imp + 12 * (size_t)wj.row_src[d] + 3u * q;
+                st3(o, 0, q == 0 ? v3_make(pn[0], pt0[0], pt1[0]) : q == 1 ? v3_make(pn[1], pt0[1], pt1[1])
+                        : q == 2 ? v3_make(pn[2], pt0[2], pt1[2]) : v3_make(pn[3], pt0[3], pt1[3]));
             }
         }
         __syncthreads();  // the LDS tile is restaged by the next trip
@@ -1028,6 +1124,14 @@ void launch_solver(phys_world* w, float dt) {
     // spin of the dataflow kernels must give up, flag the step (overflow bit 4) and let the launch end
     static const bool stall = getenv("PHYS_DEBUG_FLOW_STALL") != nullptr;
     const long long timeout_ticks = stall ? 2000000ll : kFlowTimeoutTicks;
+    // warm starting (contact_solve.h): one sweep more, in front - it applies the impulses the rows start from
+    WarmJob warm{};
+    if (w->warm) {
+        warm.man_prev = w->man_prev.p; warm.geo_prev = w->man_geo_prev.p; warm.imp_prev = w->man_imp_prev.p;
+        warm.imp = w->man_imp.p; warm.row_src = w->row_src.p;
+    }
+    const uint32_t warm_sweep = w->warm ? 1u : 0u;
+    const uint32_t sweeps = w->cfg.solver_iterations + warm_sweep;
     ColorTableJob table{};
     if (w->ctab_job_pending) {
         table.tab = reinterpret_cast<ulonglong2*>(w->ctab.p);
@@ -1051,12 +1155,12 @@ void launch_solver(phys_world* w, float dt) {
           hipLaunchKernelGGL(k_rows_build<true>, grid_for_count(m_hint), tb, 0, s, w->counters.p, rows, sp, w->row_src.p, w->man_geo.p,
                              w->pos.p, w->vel.p, inertia, stride, w->man_color.p,
                              w->color_state.p, flow ? (stall ? 2 : 1) : 0, table, w->cluster_slot.p, w->body_shared.p,
-                             w->cluster_step ? w->cluster_slots : 0u, w->cluster_count);
+                             w->cluster_step ? w->cluster_slots : 0u, w->cluster_count, warm);
       else
           hipLaunchKernelGGL(k_rows_build<false>, grid_for_count(m_hint), tb, 0, s, w->counters.p, rows, sp, w->row_src.p, w->man_geo.p,
                              w->pos.p, w->vel.p, inertia, stride, w->man_color.p,
                              w->color_state.p, flow ? (stall ? 2 : 1) : 0, table, w->cluster_slot.p, w->body_shared.p,
-                             w->cluster_step ? w->cluster_slots : 0u, w->cluster_count); }
+                             w->cluster_step ? w->cluster_slots : 0u, w->cluster_count, warm); }
     if (flow) {
         if (cluster) {
             PHYS_PROF(w, PHYS_STAGE_SOLVE_CLUSTER);
@@ -1067,7 +1171,7 @@ void launch_solver(phys_world* w, float dt) {
         const bool quad = m_hint <= kFlowQuadMaxManifolds;  // four lanes per manifold while the hop latency is everything
         const uint32_t threads = 256u;
         const uint32_t rows_per_item = quad ? threads / 4 : threads;
-        uint64_t items = (uint64_t)w->cfg.solver_iterations * ((m_hint * 5 / 4 + rows_per_item - 1) / rows_per_item) + 1;
+        uint64_t items = (uint64_t)sweeps * ((m_hint * 5 / 4 + rows_per_item - 1) / rows_per_item) + 1;
         const uint64_t most = quad ? 224 : 256;
         if (items > most) items = most;  // the remaining items are taken by the same workgroups
         PHYS_PROF(w, PHYS_STAGE_SOLVE_FLOW);
@@ -1077,10 +1181,10 @@ void launch_solver(phys_world* w, float dt) {
         static const char* pipe_env = getenv("PHYS_DEBUG_FLOW_PIPELINE");
         const uint64_t per_color = m_hint / (h.valid && h.n_colors ? h.n_colors : 1u);
         const uint32_t pipeline = pipe_env ? (uint32_t)(pipe_env[0] == '1') : (uint32_t)(4 * per_color >= threads * items);
-#define PHYS_FLOW_ARGS dim3((unsigned)items), dim3(threads), 0, s, w->counters.p, w->cfg.solver_iterations, \
+#define PHYS_FLOW_ARGS dim3((unsigned)items), dim3(threads), 0, s, w->counters.p, sweeps, \
                        w->flow_epoch, rows, sp.friction, inertia, stride, w->vel.p, w->flow_vel.p, (uint32_t)w->n, timeout_ticks
-        if (quad) { if (diag) hipLaunchKernelGGL(k_solve_flow_quad<true>, PHYS_FLOW_ARGS); else hipLaunchKernelGGL(k_solve_flow_quad<false>, PHYS_FLOW_ARGS); }
-        else { if (diag) hipLaunchKernelGGL(k_solve_flow<true>, PHYS_FLOW_ARGS, pipeline); else hipLaunchKernelGGL(k_solve_flow<false>, PHYS_FLOW_ARGS, pipeline); }
+        if (quad) { if (diag) hipLaunchKernelGGL(k_solve_flow_quad<true>, PHYS_FLOW_ARGS, warm_sweep, warm); else hipLaunchKernelGGL(k_solve_flow_quad<false>, PHYS_FLOW_ARGS, warm_sweep, warm); }
+        else { if (diag) hipLaunchKernelGGL(k_solve_flow<true>, PHYS_FLOW_ARGS, pipeline, warm_sweep, warm); else hipLaunchKernelGGL(k_solve_flow<false>, PHYS_FLOW_ARGS, pipeline, warm_sweep, warm); }
 #undef PHYS_FLOW_ARGS
         return;
     }
@@ -1106,32 +1210,33 @@ void launch_solver(phys_world* w, float dt) {
         if (b > 16384) b = 16384;
         return dim3((unsigned)(b ? b : 1));
     };
-    for (uint32_t it = 0; it < w->cfg.solver_iterations; ++it) {
+    for (uint32_t it = 0; it < sweeps; ++it) {
+        const int apply_only = warm_sweep && it == 0 ? 1 : 0, last = it + 1 == sweeps ? 1 : 0;
         for (uint32_t col = 0; col < big; ++col) {
             PHYS_PROF(w, PHYS_STAGE_SOLVE);
             if (color_kernel_mode == 2 || (color_kernel_mode == 0 && h.color_count[col] <= kQuadColorMaxRows)) {
                 if (diag)
                     hipLaunchKernelGGL(k_solve_color_quad<true>, grid_for_quads(h.color_count[col]), tb, 0, s, w->counters.p, col, rows,
-                                       sp.friction, inertia, stride, w->vel.p, (uint32_t)w->n);
+                                       sp.friction, inertia, stride, w->vel.p, (uint32_t)w->n, apply_only, last, warm);
                 else
                     hipLaunchKernelGGL(k_solve_color_quad<false>, grid_for_quads(h.color_count[col]), tb, 0, s, w->counters.p, col, rows,
-                                       sp.friction, inertia, stride, w->vel.p, (uint32_t)w->n);
+                                       sp.friction, inertia, stride, w->vel.p, (uint32_t)w->n, apply_only, last, warm);
                 continue;
             }
             if (diag)
                 hipLaunchKernelGGL(k_solve_color<true>, grid_for_count(h.color_count[col]), tb, 0, s, w->counters.p, col, rows,
-                                   sp.friction, inertia, stride, w->vel.p, ablate, (uint32_t)w->n);
+                                   sp.friction, inertia, stride, w->vel.p, ablate, (uint32_t)w->n, apply_only, last, warm);
             else
                 hipLaunchKernelGGL(k_solve_color<false>, grid_for_count(h.color_count[col]), tb, 0, s, w->counters.p, col, rows,
-                                   sp.friction, inertia, stride, w->vel.p, ablate, (uint32_t)w->n);
+                                   sp.friction, inertia, stride, w->vel.p, ablate, (uint32_t)w->n, apply_only, last, warm);
         }
         PHYS_PROF(w, PHYS_STAGE_SOLVE_TAIL);
         if (diag)
             hipLaunchKernelGGL(k_solve_tail<true>, dim3(1), dim3(kTailThreads), 0, s, w->counters.p, big, rows, sp.friction,
-                               inertia, stride, w->vel.p);
+                               inertia, stride, w->vel.p, apply_only, last, warm);
         else
             hipLaunchKernelGGL(k_solve_tail<false>, dim3(1), dim3(kTailThreads), 0, s, w->counters.p, big, rows, sp.friction,
-                               inertia, stride, w->vel.p);
+                               inertia, stride, w->vel.p, apply_only, last, warm);
     }
 }
 

@@ -243,6 +243,13 @@ struct phys_world {
     // depth}, 32 bytes spare): k_rows_build reads it through the row permutation, and seven scattered 4-to-64-byte
     // accesses per row had cost it 896 bytes of line fetches for 88 useful ones
     phys::DevBuf<float> man_geo;
+    // warm starting (contact_solve.h): the geometry records of the PREVIOUS update (the two buffers swap every update), the
+    // accumulated impulses every manifold's solve ended with (12 floats = three float4 per manifold: {pn, pt0, pt1} x 4
+    // points, packed; this update's / the previous one's), and per manifold of this update the index of the same pair's
+    // manifold in the previous update (from the colour table's value word; ~0: none)
+    phys::DevBuf<float> man_geo_prev, man_imp, man_imp_prev;
+    phys::DevBuf<uint32_t> man_prev;
+    bool warm = false;  // warm starting is on for this world (not PHYS_FLAG_NO_WARM_START, manifold indices fit the table's 26 bits)
     phys::DevBuf<uint64_t> man_prio;
     // persistent colouring: two hash tables (this update's / the previous update's), key -> colour
     phys::DevBuf<uint32_t> unc_list;  // 2 x max_manifolds: ids of the manifolds uncoloured at the start of a round (ping-pong)

@@ -19,6 +19,7 @@ pub const PHYS_FLAG_SOLVER_PER_COLOR: u32 = 0x10;
 pub const PHYS_FLAG_SHARED_GPU: u32 = 0x20;
 pub const PHYS_FLAG_SOLVER_CLUSTER: u32 = 0x40;
 pub const PHYS_FLAG_EXCLUSIVE_GPU: u32 = 0x80;
+pub const PHYS_FLAG_NO_WARM_START: u32 = 0x100;
 
 #[repr(C)]
 #[derive(Clone, Copy)]

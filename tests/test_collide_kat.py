@@ -213,6 +213,27 @@ def test_symmetric_head_on_hit_conserves_linear_momentum():
     assert abs(lin[0, 0]) < 0.3  # inelastic: approach velocity removed
 
 
+def test_warm_started_stack_stands_where_a_cold_one_creeps():
+    """contact_solve.h warm starting: a column of 12 unit cubes, eight iterations. Started every update from the impulses
+    the previous update ended with, the column is at rest after 4 s (bottom cube at y = 1 to 2e-4, every cube within 3e-3
+    of its lattice height, speeds below 0.1); from zero every update (PHYS_FLAG_NO_WARM_START, rounds 1-2) eight iterations
+    never carry the column: it has sunk by more than 0.1 and keeps creeping."""
+    from physics_amd import FLAG_NO_WARM_START
+    out = {}
+    for label, extra in (("warm", 0), ("cold", FLAG_NO_WARM_START)):
+        w = world(FLAG_COLLISIONS | FLAG_GROUND_PLANE | extra)
+        pos = scenes.lattice(1, 12, 1, 2.0, 1.0, 0.0)
+        st, he = boxes(len(pos))
+        w.set_bodies(pos, shape_type=st, half_extent=he)
+        w.update_n(DT, 240)
+        out[label] = (w.get_transforms()[0], w.get_velocities()[0])
+    y_warm, v_warm = out["warm"][0][:, 1], out["warm"][1]
+    assert abs(y_warm[0] - 1.0) < 2e-4 and np.abs(y_warm - (1.0 + 2.0 * np.arange(12))).max() < 3e-3, y_warm
+    assert np.abs(v_warm).max() < 0.1
+    y_cold = out["cold"][0][:, 1]
+    assert (1.0 + 2.0 * 11) - y_cold[-1] > 0.1, y_cold
+
+
 def test_colouring_is_proper_and_order_independent():
     sc = scenes.c3(6, 5, 6)
     w = ob.OracleWorld(sc.config(), trig=ob.TRIG_DET)

@@ -324,6 +324,22 @@ def test_c2_10k_cubes_1000_steps_north_star_tolerance():
     assert w.get_stats().n_manifolds > 10000
 
 
+@pytest.mark.parametrize("scene", ["c1", "tower", "mixed"])
+def test_cold_solver_flag_equals_the_oracle_too(scene):
+    """PHYS_FLAG_NO_WARM_START (the solver of rounds 1-2: every update from zero impulses, no sweep 0) stays a supported
+    path: bit for bit against the oracle run with the same flag - and different from the warm-started run."""
+    import physics_amd
+    from physics_amd import scenes
+    sc = {"c1": scenes.c1, "tower": lambda: scenes.c5(4, 40, 4), "mixed": lambda: scenes.c3(8, 6, 8)}[scene]()
+    sc.flags |= physics_amd.FLAG_NO_WARM_START
+    w, o = _run_scene(sc, 200, 50)
+    warm = physics_amd.World(sc.config(flags=sc.flags & ~physics_amd.FLAG_NO_WARM_START))
+    sc.populate(warm)
+    warm.update_n(DT, 200)
+    warm.sync()
+    assert not np.array_equal(warm.get_transforms()[0], w.get_transforms()[0]), "the flag changed nothing"
+
+
 @pytest.mark.parametrize("iterations", [1, 2, 5])
 def test_solver_iteration_counts(iterations):
     """Tickets of the dataflow solver are iteration * degree + rank: the first and the last iteration are special
