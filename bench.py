@@ -60,6 +60,12 @@ WORKLOAD_NAMES = {"t1m_settled": "T_1M_cubes_settled"}
 ROOFLINE_STAGE = {"ref_1m": "step_full", "ref_cg": "constraints", "c4": "pairs"}
 
 
+# warm starting (every bench scene), per manifold in k_rows_build: index of the previous manifold 4, its
+# geometry record 96 and impulse record 48 (a pile at rest matches nearly every manifold); + the starting impulses
+# written, 12 per contact point
+WARM_ROWS = 148
+
+
 def stage_bytes(stage, st, iters, cluster=False):
     """Algorithmic HBM bytes of one STEP spent in `stage` (formulas: DESIGN.md 'algorithmic bytes').
     cluster: the step ran the cluster solver, whose rows are compact and built without reading the bodies."""
@@ -79,24 +85,28 @@ def stage_bytes(stage, st, iters, cluster=False):
     if stage == "pairs":
         return 24 * n + 8 * p
     if stage == "narrow":
-        return 96 * p + 44 * st["n_ground_manifolds"] + 100 * m
+        # + warm starting: index of the pair's previous manifold 4, this update's impulse record zeroed 48
+        return 96 * p + 44 * st["n_ground_manifolds"] + 100 * m + 52 * m
     if stage == "color":
         return 28 * m  # ids + priority + colour + slot, once
     if stage == "rows" and cluster:
         # manifold record read (ids, count, normal 24 + 16 per point), compact row written (32 + 16 per point),
         # permutation + colour 8, per body side {used mask 8, cluster slot 4, remote-colour mask 8}
-        return (24 + 32 + 8) * m + 32 * k + 20 * (m + mb)
+        return (24 + 32 + 8) * m + 32 * k + 20 * (m + mb) + WARM_ROWS * m + 12 * k
     if stage == "rows":
-        return 100 * m + 24 * m + 76 * k + 52 * (m + mb)
+        return 100 * m + 24 * m + 76 * k + 52 * (m + mb) + WARM_ROWS * m + 12 * k
     if stage == "solve_cluster":
         # compact rows streamed once per iteration: header + normal 32 per manifold; per point {contact point, bias} 16,
-        # accumulated impulses 12 read + 12 written, row masses 12 read (written once); body velocities stay in LDS
-        return iters * (32 * m + 52 * k)
+        # accumulated impulses 12 read + 12 written, row masses 12 read (written once); body velocities stay in LDS.
+        # Warm starting: sweep 0 reads header, normal, points and the starting impulses and writes the row masses
+        # (32 m + 40 k); the last sweep leaves the 48-byte impulse record of every manifold
+        return iters * (32 * m + 52 * k) + (32 * m + 40 * k) + 48 * m
     if stage in ("solve", "solve_flow"):
         # (k_solve_flow makes all iterations in one launch; same job, same compulsory bytes)
         # per body and iteration: v, w read 24 + written 24, inverse mass 4, inverse inertia diagonal 12
         # (all benchmark scenes have diagonal tensors; 36 with a full tensor)
-        return iters * (24 * m + 64 * k + 64 * (m + mb))
+        # Warm starting: sweep 0 is one more pass that does not write the impulses back (12 k less); + the impulse records
+        return iters * (24 * m + 64 * k + 64 * (m + mb)) + (24 * m + 52 * k + 64 * (m + mb)) + 48 * m
     return 0
 
 
