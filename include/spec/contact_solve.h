@@ -100,6 +100,22 @@ PHYS_HD void tangent_basis(v3 n, v3* t1, v3* t2) {
  * rigid_body.rs:71) is applied as its three products; the six products with the zero off-diagonals that the general
  * product adds could only change the sign of a zero result (for finite operands). The rule is per tensor, so the
  * oracle and every solver kernel apply it alike, whatever else the world holds. */
+/* ---- fused multiply-add in the solver's row arithmetic (round 3). The reference has no contact solver, so nothing of
+ * nalgebra's operation order binds these rows (vec.h keeps that order for everything the reference does have); a row is
+ * ~1000 dependent f32 operations and the solver kernels are bound by exactly that chain. a*b + c with ONE rounding is
+ * v_fma_f32 on the device and the x86 FMA instruction on the host (the oracle is built with -mfma; without it the
+ * compiler calls libm's fmaf, which is the same correctly rounded value): the same bits on both sides, a third fewer
+ * operations. Everything below that multiplies and adds says so explicitly through these four helpers; the build keeps
+ * -ffp-contract=off, so nothing else is ever fused. */
+PHYS_HD float spec_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+/* x first, then y, then z - each product joins the sum with one rounding */
+PHYS_HD float v3_dot_f(v3 a, v3 b) { return spec_fma(a.z, b.z, spec_fma(a.y, b.y, a.x * b.x)); }
+PHYS_HD v3 v3_cross_f(v3 a, v3 b) {
+    return v3_make(spec_fma(a.y, b.z, -(a.z * b.y)), spec_fma(a.z, b.x, -(a.x * b.z)), spec_fma(a.x, b.y, -(a.y * b.x)));
+}
+/* a + b * s */
+PHYS_HD v3 v3_madd(v3 a, v3 b, float s) { return v3_make(spec_fma(b.x, s, a.x), spec_fma(b.y, s, a.y), spec_fma(b.z, s, a.z)); }
+
 PHYS_HD int m33_is_diagonal(const m33* M) {
     return M->m[1] == 0.0f && M->m[2] == 0.0f && M->m[3] == 0.0f && M->m[5] == 0.0f && M->m[6] == 0.0f && M->m[7] == 0.0f;
 }
@@ -109,11 +125,11 @@ PHYS_HD v3 inertia_mul(const m33* I, v3 a) {
 }
 
 PHYS_HD float direction_mass(v3 dir, v3 rA, v3 rB, float invMA, const m33* IA, float invMB, const m33* IB, int has_b) {
-    const v3 ra = v3_cross(rA, dir);
-    float k = invMA + v3_dot(inertia_mul(IA, ra), ra);
+    const v3 ra = v3_cross_f(rA, dir);
+    float k = invMA + v3_dot_f(inertia_mul(IA, ra), ra);
     if (has_b) {
-        const v3 rb = v3_cross(rB, dir);
-        k = (k + invMB) + v3_dot(inertia_mul(IB, rb), rb);
+        const v3 rb = v3_cross_f(rB, dir);
+        k = (k + invMB) + v3_dot_f(inertia_mul(IB, rb), rb);
     }
     return k > 0.0f ? 1.0f / k : 0.0f;
 }
@@ -164,10 +180,10 @@ typedef struct {
 
 PHYS_HD void jac_row_make(const solver_manifold_t* sm, int k, v3 dir, const m33* IA, const m33* IB, jac_row_t* j) {
     const v3 zero = v3_make(0.0f, 0.0f, 0.0f);
-    j->aA = v3_cross(sm->row[k].rA, dir);
+    j->aA = v3_cross_f(sm->row[k].rA, dir);
     j->mA = inertia_mul(IA, j->aA);
     if (sm->has_b) {
-        j->aB = v3_cross(sm->row[k].rB, dir);
+        j->aB = v3_cross_f(sm->row[k].rB, dir);
         j->mB = inertia_mul(IB, j->aB);
     } else {
         j->aB = zero; j->mB = zero;
@@ -199,17 +215,18 @@ PHYS_HD void solver_jacobians(const solver_manifold_t* sm, float invMA, const m3
 
 /* relative velocity of the contact point along dir (body B minus body A) */
 PHYS_HD float row_velocity(v3 dir, const jac_row_t* j, int has_b, v3 vA, v3 wA, v3 vB, v3 wB) {
-    const float ua = v3_dot(dir, vA) + v3_dot(j->aA, wA);
-    const float ub = has_b ? v3_dot(dir, vB) + v3_dot(j->aB, wB) : 0.0f; /* the ground does not move */
+    /* four separate dots, summed in pairs: the kernels that give a row four lanes keep one of them per lane */
+    const float ua = v3_dot_f(dir, vA) + v3_dot_f(j->aA, wA);
+    const float ub = has_b ? v3_dot_f(dir, vB) + v3_dot_f(j->aB, wB) : 0.0f; /* the ground does not move */
     return ub - ua;
 }
 
 PHYS_HD void row_apply(float lambda, v3 lA, v3 lB, const jac_row_t* j, int has_b, v3* vA, v3* wA, v3* vB, v3* wB) {
-    *vA = v3_sub(*vA, v3_scale(lA, lambda));
-    *wA = v3_sub(*wA, v3_scale(j->mA, lambda));
+    *vA = v3_madd(*vA, lA, -lambda); /* = fma(-lA, lambda, vA): negation is exact */
+    *wA = v3_madd(*wA, j->mA, -lambda);
     if (has_b) {
-        *vB = v3_add(*vB, v3_scale(lB, lambda));
-        *wB = v3_add(*wB, v3_scale(j->mB, lambda));
+        *vB = v3_madd(*vB, lB, lambda);
+        *wB = v3_madd(*wB, j->mB, lambda);
     }
 }
 
@@ -356,17 +373,17 @@ PHYS_HD void solve_manifold_geo(geo_manifold_t* gm, int make_masses, int apply_o
             for (int t = 0; t < 3; ++t) {
                 const v3 dir = t == 0 ? gm->t1 : (t == 1 ? gm->t2 : gm->n);
                 jac_row_t j;
-                j.aA = v3_cross(rA, dir);                        /* jac_row_make */
+                j.aA = v3_cross_f(rA, dir);                      /* jac_row_make */
                 j.mA = inertia_mul(IA, j.aA);
                 if (has_b) {
-                    j.aB = v3_cross(rB, dir);
+                    j.aB = v3_cross_f(rB, dir);
                     j.mB = inertia_mul(IB, j.aB);
                 } else {
                     j.aB = zero; j.mB = zero;
                 }
                 if (make_masses) {                               /* direction_mass: its ra, IA ra are aA, mA */
-                    float km = invMA + v3_dot(j.mA, j.aA);
-                    if (has_b) km = (km + invMB) + v3_dot(j.mB, j.aB);
+                    float km = invMA + v3_dot_f(j.mA, j.aA);
+                    if (has_b) km = (km + invMB) + v3_dot_f(j.mB, j.aB);
                     gm->mass[k][t] = km > 0.0f ? 1.0f / km : 0.0f;
                 }
                 if (apply_only) {                                /* solve_row_dir, sweep 0 */

@@ -783,7 +783,7 @@ __global__ __launch_bounds__(256) void k_solve_flow_quad(StepCounters* __restric
                             // solver_jacobians: lA = dir * invM; aA = r x dir, mA = I aA. The A side is subtracted
                             // by the spec: its response is stored negated (exact)
                             v3 jv, rs;
-                            if (angular) { jv = v3_cross(r, dir[t]); rs = inertia_mul(&I, jv); }
+                            if (angular) { jv = v3_cross_f(r, dir[t]); rs = inertia_mul(&I, jv); }
                             else { jv = dir[t]; rs = v3_scale(dir[t], inv_m); }
                             Jv[k][t] = jv;
                             Rs[k][t] = side_a ? v3_neg(rs) : rs;
@@ -841,10 +841,10 @@ __global__ __launch_bounds__(256) void k_solve_flow_quad(StepCounters* __restric
                             float lambda;
                             if (apply_only) {  // sweep 0 of a warm-started solve: the starting impulse reaches this lane's vector
                                 lambda = t == 0 ? pt0[k] : (t == 1 ? pt1[k] : pn[k]);
-                                x = v3_add(x, v3_scale(Rs[k][t], lambda));
+                                x = v3_madd(x, Rs[k][t], lambda);
                                 continue;
                             }
-                            const float part = v3_dot(Jv[k][t], x);
+                            const float part = v3_dot_f(Jv[k][t], x);
                             const float mine = part + quad_perm<kQuadXor1>(part);
                             const float other = quad_perm<kQuadXor2>(mine);
                             const float vrel = side_a ? other - mine : mine - other;
@@ -864,7 +864,7 @@ __global__ __launch_bounds__(256) void k_solve_flow_quad(StepCounters* __restric
                                 lambda = np - old;
                                 pn[k] = np;
                             }
-                            x = v3_add(x, v3_scale(Rs[k][t], lambda));  // row_apply
+                            x = v3_madd(x, Rs[k][t], lambda);  // row_apply
                         }
                     }
                 }
@@ -1010,7 +1010,7 @@ __global__ __launch_bounds__(256) void k_solve_color_quad(StepCounters* ctr, uin
                             // solver_jacobians: lA = dir * invM; aA = r x dir, mA = I aA; the A side is subtracted by
                             // the spec, so its response is stored negated (exact)
                             v3 jv, rs;
-                            if (angular) { jv = v3_cross(rr, dir[t]); rs = inertia_mul(&I, jv); }
+                            if (angular) { jv = v3_cross_f(rr, dir[t]); rs = inertia_mul(&I, jv); }
                             else { jv = dir[t]; rs = v3_scale(dir[t], inv_m); }
                             Jv[k][t] = jv;
                             Rs[k][t] = side_a ? v3_neg(rs) : rs;
@@ -1030,10 +1030,10 @@ __global__ __launch_bounds__(256) void k_solve_color_quad(StepCounters* ctr, uin
                     float lambda;
                     if (apply_only) {  // sweep 0 of a warm-started solve: the starting impulse reaches this lane's vector
                         lambda = t == 0 ? pt0[k] : (t == 1 ? pt1[k] : pn[k]);
-                        x = v3_add(x, v3_scale(Rs[k][t], lambda));
+                        x = v3_madd(x, Rs[k][t], lambda);
                         continue;
                     }
-                    const float part = v3_dot(Jv[k][t], x);
+                    const float part = v3_dot_f(Jv[k][t], x);
                     const float mine = part + quad_perm<kQuadXor1>(part);
                     const float other = quad_perm<kQuadXor2>(mine);
                     const float vrel = side_a ? other - mine : mine - other;
@@ -1053,7 +1053,7 @@ __global__ __launch_bounds__(256) void k_solve_color_quad(StepCounters* ctr, uin
                         lambda = np - old;
                         pn[k] = np;
                     }
-                    x = v3_add(x, v3_scale(Rs[k][t], lambda));  // row_apply
+                    x = v3_madd(x, Rs[k][t], lambda);  // row_apply
                 }
             }
         }
