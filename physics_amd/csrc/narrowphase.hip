@@ -33,7 +33,7 @@ __device__ __forceinline__ geom_t load_geom(uint32_t i, const float* __restrict_
 
 // kNpThreads: 128 for small scenes (latency-bound: more workgroups in flight, the LDS slice of the clipper
 // halves), 256 for everything else (launch_narrowphase)
-template <int kNpThreads>
+template <int kNpThreads, int kNpItems>
 __global__ __launch_bounds__(kNpThreads) void k_narrowphase(
     uint32_t n_ground /* bodies tested against the plane (0 = no ground) */, uint32_t n_owned /* pairs whose FIRST body is at
     or beyond this index are skipped (= all body slots: the ghosts of a sharded world collide like everybody else) */,
@@ -66,111 +66,135 @@ __global__ __launch_bounds__(kNpThreads) void k_narrowphase(
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t trip = 0;
     uint32_t acc_pts = 0, acc_ground = 0, acc_unc = 0;  // thread 0: statistics of this workgroup's trips, added once at the end
-    for (uint32_t base = blockIdx.x * kNpThreads; base < total; base += gridDim.x * kNpThreads, ++trip) {
-        const uint32_t idx = base + threadIdx.x;
+    // A trip is a chain of dependent round trips - pair, shapes, [test], table entry, `used` masks, barrier, slot
+    // reservation, barrier, stores - that the 12 waves a CU's LDS admits cannot hide from each other. A lane therefore
+    // tests kNpItems work items per trip, one after the other, and everything behind the test - the ballots, the two
+    // barriers, the workgroup's ONE reservation - is made once for all of them.
+    struct Item {
+        manifold_t m;
+        uint32_t a, b, col, prev_m, kept_h;
+        unsigned long long prio, seen, bit;
+        bool has, uncolored;
+    };
+    for (uint64_t base = (uint64_t)blockIdx.x * (kNpThreads * kNpItems); base < total;
+         base += (uint64_t)gridDim.x * (kNpThreads * kNpItems), ++trip) {
         uint32_t* wcount = wtot[trip & 1u][0];
         uint32_t* wpts = wtot[trip & 1u][1];
         uint32_t* wground = wtot[trip & 1u][2];
         uint32_t* wunc = wtot[trip & 1u][3];
-        manifold_t m;
-        m.count = 0;
-        uint32_t a = 0, b = PHYS_GROUND_ID;
-        ulonglong2 early = make_ulonglong2(0ull, 0ull);
-        uint32_t early_h = 0;
-        bool have_early = false;
-        if (idx < n_ground) {
-            a = idx;
-            // the fattened AABB of this step (k_step_velocity_aabb; lo.y = lowest corner - margin) rules most bodies out
-            // without their orientation being read or a corner being made: a million-cube drop has 1 % of its bodies on
-            // the plane. Conservative: a body is kept unless its AABB clears ground + margin by more than rounding.
-            const float4 g2 = reinterpret_cast<const float4*>(geo)[4 * (size_t)a + 2];
-            const float lo_y = g2.w;
-            if (lo_y <= (ground + margin) + 1.0e-3f * (1.0f + det_absf(lo_y))) {
-                const geom_t ga = load_geom(a, geo);
-                if (ga.type != PHYS_SPEC_SHAPE_NONE) collide_ground(&ga, ground, margin, &m, ws);
-            }
-        } else if (idx < total) {
-            const uint2 pr = reinterpret_cast<const uint2*>(pairs)[idx - n_ground];
-            a = pr.x; b = pr.y;
-            if (a < n_owned) {
-                // the colour-table entry this pair would keep its colour from (a random 16-byte read): asked for NOW, so
-                // that it travels while the shapes are fetched and tested instead of being one more dependent round trip
-                // behind the emission below (nearly every candidate pair of a resting pile becomes a manifold)
-                // (only where most candidate pairs DO become manifolds: a stack of aligned boxes has three sliver pairs for
-                // every contact since the sliver rule, and three wasted 64-byte line fetches out of a 100+ MB table for
-                // every useful one - launch_narrowphase decides from the counts of an earlier update)
-                if (cache_mask && early_probe) {
-                    early_h = (uint32_t)(color_priority(a, b) >> 20) & cache_mask;
-                    early = cache[early_h];
-                    have_early = true;
+        Item item[kNpItems];
+#pragma unroll
+        for (int j = 0; j < kNpItems; ++j) {
+            Item& it = item[j];
+            manifold_t& m = it.m;
+            const uint64_t idx = base + (uint64_t)j * kNpThreads + threadIdx.x;
+            m.count = 0;
+            uint32_t a = 0, b = PHYS_GROUND_ID;
+            ulonglong2 early = make_ulonglong2(0ull, 0ull);
+            uint32_t early_h = 0;
+            bool have_early = false;
+            if (idx < n_ground) {
+                a = (uint32_t)idx;
+                // the fattened AABB of this step (k_step_velocity_aabb; lo.y = lowest corner - margin) rules most bodies out
+                // without their orientation being read or a corner being made: a million-cube drop has 1 % of its bodies on
+                // the plane. Conservative: a body is kept unless its AABB clears ground + margin by more than rounding.
+                const float4 g2 = reinterpret_cast<const float4*>(geo)[4 * (size_t)a + 2];
+                const float lo_y = g2.w;
+                if (lo_y <= (ground + margin) + 1.0e-3f * (1.0f + det_absf(lo_y))) {
+                    const geom_t ga = load_geom(a, geo);
+                    if (ga.type != PHYS_SPEC_SHAPE_NONE) collide_ground(&ga, ground, margin, &m, ws);
                 }
-                const geom_t ga = load_geom(a, geo);
-                const geom_t gb = load_geom(b, geo);
-                collide_pair(&ga, &gb, margin, &m, ws);
-            }
-        }
-        const bool has = m.count > 0;
-        // ---- everything of a manifold that does not need its slot, BEFORE the workgroup's slot reservation: the kept
-        // colour (table entry asked for above; re-stamped here), the colour's mark at the two bodies, or round 0 of the
-        // colouring. Their round trips then overlap the reservation's instead of following it (the stage is a chain of
-        // dependent round trips at 12 waves per CU: one reservation with one barrier per trip instead of two with four).
-        // A manifold that turns out to be beyond the capacity has then left its marks too: that update is flagged, its
-        // solve skipped and its new manifolds never reach the table, so nothing of it survives.
-        unsigned long long prio = 0ull, seen_a = 0ull, seen_b = 0ull, bit = 0ull;
-        uint32_t col = kUncolored, prev_m = 0xFFFFFFFFu, kept_h = 0;
-        bool uncolored = false;
-        if (has) {
-            prio = color_priority(a, b);
-            // persistent colouring (contact_solve.h): a manifold that existed in the previous update keeps its
-            // colour - exact 64-bit key match in the table, stamped by the previous update; re-stamped here
-            if (cache_mask) {
-                const unsigned long long key = ((unsigned long long)a << 32) | b;
-                uint32_t h = (uint32_t)(prio >> 20) & cache_mask;
-                // bounded walk: the table is rebuilt every PHYS_COLOR_CACHE_PERIOD updates and holds 1.5 slots per manifold
-                // slot, but a chain of live and dead entries without an empty slot must end the walk, not hang the GPU
-                bool ended = false;
-                for (uint32_t walked = 0; walked < kColorTableMaxWalk; ++walked) {
-                    const ulonglong2 e = (have_early && h == early_h) ? early : cache[h];
-                    have_early = false;
-                    if (e.x == key) {
-                        if ((uint32_t)(e.y >> 32) + 1u == stamp) {
-                            col = (uint32_t)e.y & 63u;
-                            prev_m = ((uint32_t)e.y >> 6);  // the pair's manifold of the previous update
-                            kept_h = h;                     // re-stamped below, once this update's slot is known
-                        }
-                        ended = true;
-                        break;  // a dead entry of this key: no live one follows
+            } else if (idx < total) {
+                const uint2 pr = reinterpret_cast<const uint2*>(pairs)[idx - n_ground];
+                a = pr.x; b = pr.y;
+                if (a < n_owned) {
+                    // the colour-table entry this pair would keep its colour from (a random 16-byte read): asked for NOW, so
+                    // that it travels while the shapes are fetched and tested instead of being one more dependent round trip
+                    // behind the emission below (nearly every candidate pair of a resting pile becomes a manifold)
+                    // (only where most candidate pairs DO become manifolds: a stack of aligned boxes has three sliver pairs for
+                    // every contact since the sliver rule, and three wasted 64-byte line fetches out of a 100+ MB table for
+                    // every useful one - launch_narrowphase decides from the counts of an earlier update)
+                    if (cache_mask && early_probe) {
+                        early_h = (uint32_t)(color_priority(a, b) >> 20) & cache_mask;
+                        early = cache[early_h];
+                        have_early = true;
                     }
-                    if (e.x == ~0ull) { ended = true; break; }  // empty slot: never seen
-                    h = (h + 1) & cache_mask;
+                    const geom_t ga = load_geom(a, geo);
+                    const geom_t gb = load_geom(b, geo);
+                    collide_pair(&ga, &gb, margin, &m, ws);
                 }
-                // a walk given up on might have passed over a colour the oracle's map keeps: never silently (bit 6: the
-                // update is flagged and its solve skipped, like any other capacity miss)
-                if (!ended) flag_overflow(ctr, 64u);
             }
-            if (col != kUncolored) {
-                bit = 1ull << col;
-                seen_a = atomicOr(&used[a], bit);  // looked at after the barrier below
-                if (b != PHYS_GROUND_ID) seen_b = atomicOr(&used[b], bit);
-            } else {
-                uncolored = true;
-                // round 0 of the colouring: per-body maximum priority (order-independent u64 max)
-                atomicMax(&top0[a], prio);
-                if (b != PHYS_GROUND_ID) atomicMax(&top0[b], prio);
+            const bool has = m.count > 0;
+            // ---- everything of a manifold that does not need its slot, BEFORE the workgroup's slot reservation: the kept
+            // colour (table entry asked for above; re-stamped below), the colour's mark at the two bodies, or round 0 of the
+            // colouring. Their round trips then overlap the reservation's instead of following it.
+            // A manifold that turns out to be beyond the capacity has then left its marks too: that update is flagged, its
+            // solve skipped and its new manifolds never reach the table, so nothing of it survives.
+            unsigned long long prio = 0ull, seen_a = 0ull, seen_b = 0ull, bit = 0ull;
+            uint32_t col = kUncolored, prev_m = 0xFFFFFFFFu, kept_h = 0;
+            bool uncolored = false;
+            if (has) {
+                prio = color_priority(a, b);
+                // persistent colouring (contact_solve.h): a manifold that existed in the previous update keeps its
+                // colour - exact 64-bit key match in the table, stamped by the previous update; re-stamped below
+                if (cache_mask) {
+                    const unsigned long long key = ((unsigned long long)a << 32) | b;
+                    uint32_t h = (uint32_t)(prio >> 20) & cache_mask;
+                    // bounded walk: the table is rebuilt every PHYS_COLOR_CACHE_PERIOD updates and holds 1.5 slots per manifold
+                    // slot, but a chain of live and dead entries without an empty slot must end the walk, not hang the GPU
+                    bool ended = false;
+                    for (uint32_t walked = 0; walked < kColorTableMaxWalk; ++walked) {
+                        const ulonglong2 e = (have_early && h == early_h) ? early : cache[h];
+                        have_early = false;
+                        if (e.x == key) {
+                            if ((uint32_t)(e.y >> 32) + 1u == stamp) {
+                                col = (uint32_t)e.y & 63u;
+                                prev_m = ((uint32_t)e.y >> 6);  // the pair's manifold of the previous update
+                                kept_h = h;                     // re-stamped below, once this update's slot is known
+                            }
+                            ended = true;
+                            break;  // a dead entry of this key: no live one follows
+                        }
+                        if (e.x == ~0ull) { ended = true; break; }  // empty slot: never seen
+                        h = (h + 1) & cache_mask;
+                    }
+                    // a walk given up on might have passed over a colour the oracle's map keeps: never silently (bit 6: the
+                    // update is flagged and its solve skipped, like any other capacity miss)
+                    if (!ended) flag_overflow(ctr, 64u);
+                }
+                if (col != kUncolored) {
+                    bit = 1ull << col;
+                    seen_a = atomicOr(&used[a], bit);  // looked at after the barrier below
+                    if (b != PHYS_GROUND_ID) seen_b = atomicOr(&used[b], bit);
+                } else {
+                    uncolored = true;
+                    // round 0 of the colouring: per-body maximum priority (order-independent u64 max)
+                    atomicMax(&top0[a], prio);
+                    if (b != PHYS_GROUND_ID) atomicMax(&top0[b], prio);
+                }
             }
+            it.a = a; it.b = b; it.col = col; it.prev_m = prev_m; it.kept_h = kept_h;
+            it.prio = prio; it.seen = seen_a | seen_b; it.bit = bit; it.has = has; it.uncolored = uncolored;
         }
-        const unsigned long long mask = __ballot(has);
-        const unsigned long long gmask = __ballot(has && b == PHYS_GROUND_ID);
-        const unsigned long long umask = __ballot(uncolored);
-        // contact points of this wave (for the stats counter)
-        uint32_t pts = has ? (uint32_t)m.count : 0u;
+        // manifolds of the wave: item-major (all of item 0, then all of item 1), lanes in order inside an item
+        unsigned long long mask[kNpItems], umask[kNpItems];
+        uint32_t n_has = 0, n_gnd = 0, n_unc = 0, pts = 0;
+#pragma unroll
+        for (int j = 0; j < kNpItems; ++j) {
+            mask[j] = __ballot(item[j].has);
+            umask[j] = __ballot(item[j].uncolored);
+            n_has += (uint32_t)__popcll(mask[j]);
+            n_unc += (uint32_t)__popcll(umask[j]);
+            n_gnd += (uint32_t)__popcll(__ballot(item[j].has && item[j].b == PHYS_GROUND_ID));
+            pts += item[j].has ? (uint32_t)item[j].m.count : 0u;  // contact points (for the stats counter)
+        }
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) pts += (uint32_t)__shfl_xor((int)pts, off, 64);
         if (lane == 0) {
-            wcount[wave] = (uint32_t)__popcll(mask);
+            wcount[wave] = n_has;
             wpts[wave] = pts;
-            wground[wave] = (uint32_t)__popcll(gmask);
-            wunc[wave] = (uint32_t)__popcll(umask);
+            wground[wave] = n_gnd;
+            wunc[wave] = n_unc;
         }
         __syncthreads();
         if (threadIdx.x == 0) {
@@ -194,44 +218,53 @@ __global__ __launch_bounds__(kNpThreads) void k_narrowphase(
             unc_base = ub;
         }
         __syncthreads();
-        if (has) {
-            uint32_t woff = 0, uoff = 0;
-            for (int k = 0; k < wave; ++k) { woff += wcount[k]; uoff += wunc[k]; }
-            const uint64_t slot = (uint64_t)block_base + woff + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-            if (slot < max_manifolds) {
-                man_a[slot] = a;
-                man_b[slot] = b;
-                man_prio[slot] = prio;
-                man_color[slot] = col;
-                // a kept entry is re-stamped with this update's manifold index (one 8-byte store to the line the probe read)
-                if (col != kUncolored) cache[kept_h].y = ((unsigned long long)stamp << 32) | ((unsigned long long)((uint32_t)slot & 0x3FFFFFFu) << 6) | col;
-                if (man_prev) {
-                    man_prev[slot] = prev_m;
-                    float4* imp = reinterpret_cast<float4*>(man_imp) + 3 * slot;
-                    imp[0] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); imp[1] = imp[0]; imp[2] = imp[0];
-                }
-                // (Measured and dropped: staging the records of a wave in LDS and copying them out as whole 128-byte lines -
-                // 4.5 write requests per manifold become 2 - left the kernel at 0.52 ms on C5: it waits on its chain of
-                // dependent round trips, not on the write path.)
-                float4* o = reinterpret_cast<float4*>(man_geo) + 8 * slot;  // one 128-byte line per manifold, 96 bytes used
-                o[0] = make_float4(__uint_as_float(a), __uint_as_float(b), __uint_as_float((uint32_t)m.count),
-                                   __uint_as_float(col != kUncolored ? 1u : 0u) /* colour kept: already in the table */);
-                o[1] = make_float4(m.normal.x, m.normal.y, m.normal.z, 0.0f);
+        uint32_t woff = 0, uoff = 0;
+        for (int k = 0; k < wave; ++k) { woff += wcount[k]; uoff += wunc[k]; }
+        const unsigned long long below = (1ull << lane) - 1ull;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) o[2 + k] = make_float4(m.pt[k].x, m.pt[k].y, m.pt[k].z, m.depth[k]);
+        for (int j = 0; j < kNpItems; ++j) {
+            const Item& it = item[j];
+            if (it.has) {
+                const manifold_t& m = it.m;
+                const uint32_t a = it.a, b = it.b, col = it.col;
+                const uint64_t slot = (uint64_t)block_base + woff + (uint32_t)__popcll(mask[j] & below);
+                if (slot < max_manifolds) {
+                    man_a[slot] = a;
+                    man_b[slot] = b;
+                    man_prio[slot] = it.prio;
+                    man_color[slot] = col;
+                    // a kept entry is re-stamped with this update's manifold index (one 8-byte store to the line the probe read)
+                    if (col != kUncolored) cache[it.kept_h].y = ((unsigned long long)stamp << 32) | ((unsigned long long)((uint32_t)slot & 0x3FFFFFFu) << 6) | col;
+                    if (man_prev) {
+                        man_prev[slot] = it.prev_m;
+                        float4* imp = reinterpret_cast<float4*>(man_imp) + 3 * slot;
+                        imp[0] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); imp[1] = imp[0]; imp[2] = imp[0];
+                    }
+                    // (Measured and dropped: staging the records of a wave in LDS and copying them out as whole 128-byte lines -
+                    // 4.5 write requests per manifold become 2 - left the kernel at 0.52 ms on C5: it waits on its chain of
+                    // dependent round trips, not on the write path.)
+                    float4* o = reinterpret_cast<float4*>(man_geo) + 8 * slot;  // one 128-byte line per manifold, 96 bytes used
+                    o[0] = make_float4(__uint_as_float(a), __uint_as_float(b), __uint_as_float((uint32_t)m.count),
+                                       __uint_as_float(col != kUncolored ? 1u : 0u) /* colour kept: already in the table */);
+                    o[1] = make_float4(m.normal.x, m.normal.y, m.normal.z, 0.0f);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) o[2 + k] = make_float4(m.pt[k].x, m.pt[k].y, m.pt[k].z, m.depth[k]);
+                }
+                if (it.uncolored) {
+                    // (a manifold beyond the capacity - update flagged, never solved - names the last slot: the list must hold
+                    // ids of stored manifolds only, whatever else happens to that update)
+                    const uint32_t at = unc_base + uoff + (uint32_t)__popcll(umask[j] & below);
+                    unc_list[at < max_manifolds ? at : (uint32_t)max_manifolds - 1u] =
+                        slot < max_manifolds ? (uint32_t)slot : (uint32_t)max_manifolds - 1u;
+                } else if ((it.seen & it.bit) != 0ull) {
+                    // order-independent. A kept colour that was ALREADY in use at one of the bodies means the previous
+                    // colouring was not proper (it saturated at PHYS_MAX_COLORS): two rows of one colour on one body
+                    // would race in the solver, so the step is flagged like any other colour overflow (no solve)
+                    flag_overflow(ctr, 4u);
+                }
             }
-            if (uncolored) {
-                // (a manifold beyond the capacity - update flagged, never solved - names the last slot: the list must hold
-                // ids of stored manifolds only, whatever else happens to that update)
-                const uint32_t at = unc_base + uoff + (uint32_t)__popcll(umask & ((1ull << lane) - 1ull));
-                unc_list[at < max_manifolds ? at : (uint32_t)max_manifolds - 1u] =
-                    slot < max_manifolds ? (uint32_t)slot : (uint32_t)max_manifolds - 1u;
-            } else if (((seen_a | seen_b) & bit) != 0ull) {
-                // order-independent. A kept colour that was ALREADY in use at one of the bodies means the previous
-                // colouring was not proper (it saturated at PHYS_MAX_COLORS): two rows of one colour on one body
-                // would race in the solver, so the step is flagged like any other colour overflow (no solve)
-                flag_overflow(ctr, 4u);
-            }
+            woff += (uint32_t)__popcll(mask[j]);
+            uoff += (uint32_t)__popcll(umask[j]);
         }
         // (block_base / unc_base are rewritten behind the next trip's first barrier, which every wave reaches only after it
         // has placed this trip's manifolds; the per-wave totals alternate between two sets)
@@ -752,11 +785,11 @@ void launch_narrowphase(phys_world* w) {
         std::swap(w->man_imp.p, w->man_imp_prev.p);
     }
     PHYS_PROF(w, PHYS_STAGE_NARROW);
-#define PHYS_NP_LAUNCH(T)                                                                                              \
+#define PHYS_NP_LAUNCH(T, kItems)                                                                                              \
     do {                                                                                                               \
-        uint64_t blocks = (work + T - 1) / T;                                                                          \
+        uint64_t blocks = (work + T * kItems - 1) / (T * kItems);                                                      \
         if (blocks > 256 * 16) blocks = 256 * 16;                                                                      \
-        hipLaunchKernelGGL((k_narrowphase<T>), dim3((unsigned)blocks), dim3(T), 0, w->stream, n_ground, n_owned, w->pairs.p, \
+        hipLaunchKernelGGL((k_narrowphase<T, kItems>), dim3((unsigned)blocks), dim3(T), 0, w->stream, n_ground, n_owned, w->pairs.p, \
                            w->max_pairs, w->geo.p, w->cfg.contact_margin, \
                            w->cfg.ground_height, w->max_manifolds, w->man_a.p, w->man_b.p,                             \
                            w->man_color.p, w->man_geo.p, w->man_prio.p, w->color_state.p,                              \
@@ -767,7 +800,10 @@ void launch_narrowphase(phys_world* w) {
     // 128 threads only while the whole stage is a few workgroups (C2: 10k manifolds); measured at 230k manifolds (C3):
     // 0.175 ms with 128 threads, 0.133 with 256; at 2.9M (C5): 0.86 vs 0.55, and 512 no better than 256
     const bool few = w->hint.valid ? w->hint.n_manifolds <= 32768u : n <= 200000u;
-    if (np_threads_env ? np_threads_env == 128 : few) PHYS_NP_LAUNCH(128); else PHYS_NP_LAUNCH(256);
+    static const int np_items_env = getenv("PHYS_DEBUG_NP_ITEMS") ? atoi(getenv("PHYS_DEBUG_NP_ITEMS")) : 0;  // measurements
+    if (np_threads_env ? np_threads_env == 128 : few) PHYS_NP_LAUNCH(128, 1);
+    else if (np_items_env == 1) PHYS_NP_LAUNCH(256, 1);
+    else PHYS_NP_LAUNCH(256, 2);
 #undef PHYS_NP_LAUNCH
 }
 
