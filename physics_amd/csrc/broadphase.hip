@@ -154,10 +154,14 @@ __global__ __launch_bounds__(kScanThreads) void k_scan_final(const uint32_t* __r
     }
 }
 
-// small tables (<= 32768 buckets): the whole exclusive scan in ONE workgroup, one launch instead of three
+// small tables (<= 32768 counters): the whole exclusive scan in ONE workgroup, one launch instead of three
+// (measured at 64 items per thread, for the cluster solver's 672 x 64 segment table: 25.6 us - one workgroup's lanes read
+// 256-byte runs each, every line is touched by eight load instructions - against 3 x 4.8 us for the three launches)
 constexpr int kScanSmallThreads = 1024;
 constexpr int kScanSmallItems = 32;
-__global__ __launch_bounds__(kScanSmallThreads) void k_scan_small(const uint32_t* __restrict__ in, uint32_t count /* multiple of 4 */,
+// ZERO_IN: the counters are left zeroed for their next use (a per-step histogram then needs no memset launch of its own)
+template <bool ZERO_IN>
+__global__ __launch_bounds__(kScanSmallThreads) void k_scan_small(uint32_t* __restrict__ in, uint32_t count /* multiple of 4 */,
                                                                   uint32_t* __restrict__ out /*count + 1*/) {
     __shared__ uint32_t wtot[kScanSmallThreads / 64];
     const uint32_t base = threadIdx.x * kScanSmallItems;
@@ -166,7 +170,10 @@ __global__ __launch_bounds__(kScanSmallThreads) void k_scan_small(const uint32_t
 #pragma unroll
     for (int k = 0; k < kScanSmallItems / 4; ++k) {
         v[k] = make_uint4(0u, 0u, 0u, 0u);
-        if (base + 4 * k < count) v[k] = *reinterpret_cast<const uint4*>(in + base + 4 * k);
+        if (base + 4 * k < count) {
+            v[k] = *reinterpret_cast<const uint4*>(in + base + 4 * k);
+            if (ZERO_IN) *reinterpret_cast<uint4*>(in + base + 4 * k) = make_uint4(0u, 0u, 0u, 0u);
+        }
         sum += v[k].x + v[k].y + v[k].z + v[k].w;
     }
     const uint32_t inc = wave_inclusive_scan(sum);
@@ -820,7 +827,7 @@ int32_t collision_alloc(phys_world* w) {
             PHYS_HIP_TRY(w->man_geo_prev.resize(32 * M));
             PHYS_HIP_TRY(w->man_imp.resize(12 * M));
             PHYS_HIP_TRY(w->man_imp_prev.resize(12 * M));
-            PHYS_HIP_TRY(w->man_prev.resize(M));
+            PHYS_HIP_TRY(w->man_prev.resize(4));  // only its address is used: "warm starting is on" (the index itself is in man_geo)
         }
         PHYS_HIP_TRY(w->man_prio.resize(M));
         PHYS_HIP_TRY(w->row_src.resize(M));
@@ -861,10 +868,14 @@ int32_t collision_alloc(phys_world* w) {
 }
 
 // exclusive scan of `count` (a multiple of 4) counters into out[count + 1] on the world's stream
-void launch_exclusive_scan(phys_world* w, const uint32_t* in, uint32_t count, uint32_t* out) {
+bool scan_is_one_launch(uint32_t count) { return count <= (uint32_t)(kScanSmallThreads * kScanSmallItems); }
+
+// zero_in: only honoured by the one-launch scan (scan_is_one_launch(count)); the caller zeroes the counters itself otherwise
+void launch_exclusive_scan(phys_world* w, uint32_t* in, uint32_t count, uint32_t* out, bool zero_in) {
     hipStream_t s = w->stream;
-    if (count <= (uint32_t)(kScanSmallThreads * kScanSmallItems)) {
-        hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(kScanSmallThreads), 0, s, in, count, out);
+    if (scan_is_one_launch(count)) {
+        if (zero_in) hipLaunchKernelGGL(k_scan_small<true>, dim3(1), dim3(kScanSmallThreads), 0, s, in, count, out);
+        else hipLaunchKernelGGL(k_scan_small<false>, dim3(1), dim3(kScanSmallThreads), 0, s, in, count, out);
         return;
     }
     const uint32_t nblk = (count + kScanChunk - 1) / kScanChunk;
@@ -898,7 +909,7 @@ void build_sorted_grid(phys_world* w) {
                        w->bucket_cursor.p, w->bucket_count.p); }
     if (T <= (uint32_t)(kScanSmallThreads * kScanSmallItems) && T % 4 == 0) {
         PHYS_PROF(w, PHYS_STAGE_GRID);
-        hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(kScanSmallThreads), 0, s, w->bucket_count.p, T, w->bucket_start.p);
+        hipLaunchKernelGGL(k_scan_small<false>, dim3(1), dim3(kScanSmallThreads), 0, s, w->bucket_count.p, T, w->bucket_start.p);
     } else {
         const uint32_t nblk = (T + kScanChunk - 1) / kScanChunk;
         uint32_t* used = w->scan_block_sums.p + (w->scan_block_sums.n / 2);  // second half of the buffer

@@ -102,6 +102,7 @@ int32_t cluster_assign(phys_world* w, const float* pos /* host, 3 * n_owned */) 
         PHYS_HIP_TRY(w->cluster_body.resize(homes_max));
         PHYS_HIP_TRY(w->body_shared.resize(2 * n));
         PHYS_HIP_TRY(w->seg_count.resize((size_t)clusters_max * PHYS_MAX_COLORS + 4));
+        PHYS_HIP_TRY(hipMemsetAsync(w->seg_count.p, 0, ((size_t)clusters_max * PHYS_MAX_COLORS + 4) * 4, w->stream));
         PHYS_HIP_TRY(w->seg_start.resize((size_t)clusters_max * PHYS_MAX_COLORS + 4));
         PHYS_HIP_TRY(w->man_rank.resize(w->max_manifolds));
         PHYS_HIP_TRY(w->active_flag.resize(n + 4));
@@ -141,6 +142,7 @@ int32_t cluster_assign(phys_world* w, const float* pos /* host, 3 * n_owned */) 
     PHYS_HIP_TRY(w->cluster_body.resize(body_of.size()));
     PHYS_HIP_TRY(w->body_shared.resize(2 * n));  // 64-bit mask of remote colours per body
     PHYS_HIP_TRY(w->seg_count.resize((size_t)clusters * PHYS_MAX_COLORS + 4));
+    PHYS_HIP_TRY(hipMemsetAsync(w->seg_count.p, 0, ((size_t)clusters * PHYS_MAX_COLORS + 4) * 4, w->stream));
     PHYS_HIP_TRY(w->seg_start.resize((size_t)clusters * PHYS_MAX_COLORS + 4));
     PHYS_HIP_TRY(w->man_rank.resize(w->max_manifolds));
     PHYS_HIP_TRY(hipMemcpyAsync(w->cluster_slot.p, cslot.data(), 4 * n, hipMemcpyHostToDevice, w->stream));
@@ -279,7 +281,6 @@ __global__ __launch_bounds__(256) void k_cluster_place(uint64_t max_manifolds, c
     }
 }
 
-void launch_exclusive_scan(phys_world* w, const uint32_t* in, uint32_t count, uint32_t* out);  // broadphase.hip
 
 // called by launch_coloring in place of the colour-major placement
 void launch_cluster_sort(phys_world* w, unsigned blocks) {
@@ -299,15 +300,18 @@ void launch_cluster_sort(phys_world* w, unsigned blocks) {
         hipLaunchKernelGGL(k_active_flags, g, b, 0, s, (uint32_t)w->n_owned, w->color_state.p, w->bucket_of.p, w->bucket_cursor.p,
                            w->bucket_start.p, w->active_flag.p);
         const uint32_t n4 = (n + 3u) & ~3u;  // the scans want a multiple of four; the total lands behind the last entry
-        launch_exclusive_scan(w, w->active_flag.p, n4, w->active_rank.p);
+        launch_exclusive_scan(w, w->active_flag.p, n4, w->active_rank.p, false);
         hipLaunchKernelGGL(k_cluster_homes, g, b, 0, s, n, (uint32_t)w->n_owned, w->color_state.p, w->bucket_of.p, w->bucket_cursor.p,
                            w->bucket_start.p, w->active_rank.p, n4, homes, w->cluster_slot.p, w->cluster_body.p, w->counters.p);
     }
-    (void)hipMemsetAsync(w->seg_count.p, 0, (size_t)bins * 4, s);
+    // the per-(cluster, colour) counters: all zero on entry - at first use by the allocation's memset (cluster_assign), later
+    // because the one-launch scan leaves them zeroed behind it (one memset launch less per update)
+    const bool self_zeroing = scan_is_one_launch(bins);
+    if (!self_zeroing) (void)hipMemsetAsync(w->seg_count.p, 0, (size_t)bins * 4, s);
     (void)hipMemsetAsync(w->body_shared.p, 0, (size_t)w->n * 8, s);
     hipLaunchKernelGGL(k_cluster_keys, dim3(blocks), dim3(256), 0, s, w->max_manifolds, w->man_a.p, w->man_b.p, w->man_color.p,
                        w->cluster_slot.p, w->cluster_slots, w->cluster_count, w->seg_count.p, w->man_rank.p, w->body_shared.p, w->counters.p);
-    launch_exclusive_scan(w, w->seg_count.p, bins, w->seg_start.p);
+    launch_exclusive_scan(w, w->seg_count.p, bins, w->seg_start.p, self_zeroing);
     hipLaunchKernelGGL(k_cluster_place, dim3(blocks), dim3(256), 0, s, w->max_manifolds, w->man_a.p, w->man_b.p, w->man_color.p,
                        w->cluster_slot.p, w->cluster_slots, w->cluster_count, w->seg_start.p, w->man_rank.p, w->row_src.p, w->counters.p);
 }

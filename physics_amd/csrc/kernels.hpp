@@ -189,7 +189,8 @@ int32_t halo_pairs(phys_world* w, const void* dev_remote, uint64_t n_remote, uin
 // cluster.hip
 int32_t cluster_assign(phys_world* w, const float* host_pos);
 void launch_cluster_sort(phys_world* w, unsigned blocks);
-void launch_exclusive_scan(phys_world* w, const uint32_t* in, uint32_t count, uint32_t* out);  // broadphase.hip; count % 4 == 0
+void launch_exclusive_scan(phys_world* w, uint32_t* in, uint32_t count, uint32_t* out, bool zero_in);  // broadphase.hip; count % 4 == 0
+bool scan_is_one_launch(uint32_t count);  // ... in which case zero_in leaves the counters zeroed behind the scan
 bool cluster_plan_dynamic(phys_world* w);  // cluster.hip: clusters / slots of this update from the hint (dynamic clusters)
 void launch_solve_cluster(phys_world* w, void* row_all, uint64_t cap, float friction, const float* inertia, uint32_t stride,
                           bool diag, long long timeout_ticks);

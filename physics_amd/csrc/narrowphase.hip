@@ -46,7 +46,8 @@ __global__ __launch_bounds__(kNpThreads) void k_narrowphase(
     uint32_t cache_mask /* 0 = keep nothing this update */, uint32_t early_probe /* ask for the table entry before the shapes
     are tested */, uint32_t stamp /* of this update */,
     uint32_t* __restrict__ unc_list /* ids of the manifolds that did not keep a colour: round 0 of the colouring */,
-    uint32_t* __restrict__ man_prev /* warm starting: index of the pair's manifold in the previous update (null: off) */,
+    const uint32_t* __restrict__ man_prev /* warm starting on (non-null; the index of the pair's previous manifold itself
+    travels in the manifold record) */,
     float* __restrict__ man_imp /* ... and this update's impulse records, zeroed here (a solve that never runs leaves zeros) */,
     StepCounters* __restrict__ ctr) {
     // per-wave totals of a trip, in two sets used alternately: a wave may start the next trip (and post its totals) while
@@ -236,7 +237,6 @@ __global__ __launch_bounds__(kNpThreads) void k_narrowphase(
                     // a kept entry is re-stamped with this update's manifold index (one 8-byte store to the line the probe read)
                     if (col != kUncolored) cache[it.kept_h].y = ((unsigned long long)stamp << 32) | ((unsigned long long)((uint32_t)slot & 0x3FFFFFFu) << 6) | col;
                     if (man_prev) {
-                        man_prev[slot] = it.prev_m;
                         float4* imp = reinterpret_cast<float4*>(man_imp) + 3 * slot;
                         imp[0] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); imp[1] = imp[0]; imp[2] = imp[0];
                     }
@@ -244,9 +244,12 @@ __global__ __launch_bounds__(kNpThreads) void k_narrowphase(
                     // 4.5 write requests per manifold become 2 - left the kernel at 0.52 ms on C5: it waits on its chain of
                     // dependent round trips, not on the write path.)
                     float4* o = reinterpret_cast<float4*>(man_geo) + 8 * slot;  // one 128-byte line per manifold, 96 bytes used
+                    // {a, b, count, kept colour + 1 (0: new in this update, coloured later: man_color)} {normal, index of the pair's
+                    // manifold in the previous update or ~0}: what k_rows_build would otherwise gather, 4 bytes out of a 64-byte
+                    // sector each, from two more arrays through the row permutation
                     o[0] = make_float4(__uint_as_float(a), __uint_as_float(b), __uint_as_float((uint32_t)m.count),
-                                       __uint_as_float(col != kUncolored ? 1u : 0u) /* colour kept: already in the table */);
-                    o[1] = make_float4(m.normal.x, m.normal.y, m.normal.z, 0.0f);
+                                       __uint_as_float(col != kUncolored ? col + 1u : 0u));
+                    o[1] = make_float4(m.normal.x, m.normal.y, m.normal.z, __uint_as_float(it.prev_m));
 #pragma unroll
                     for (int k = 0; k < 4; ++k) o[2 + k] = make_float4(m.pt[k].x, m.pt[k].y, m.pt[k].z, m.depth[k]);
                 }

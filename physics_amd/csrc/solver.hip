@@ -51,7 +51,7 @@ __device__ __forceinline__ m33 ld_inertia<true>(const float* __restrict__ p, uin
 
 // warm starting (contact_solve.h): where the impulses a solve ends with go, and where a row's starting impulses come from
 struct WarmJob {
-    const uint32_t* man_prev;  // null: warm starting is off (rows start from zero, no sweep 0)
+    const uint32_t* man_prev;  // null: warm starting is off (rows start from zero, no sweep 0); otherwise only a flag
     const float* geo_prev;     // 128-byte manifold records of the previous update
     const float* imp_prev;     // 12 floats per manifold: what its solve ended with
     float* imp;                // this update's (written by the last sweep of whichever solver kernel runs)
@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) void k_rows_build(StepCounters* __restrict__ c
         // with, matched point by point (contact_solve.h warm_match); zero for a new pair or with warm starting off
         float w_pn[4] = {0.0f, 0.0f, 0.0f, 0.0f}, w_pt0[4] = {0.0f, 0.0f, 0.0f, 0.0f}, w_pt1[4] = {0.0f, 0.0f, 0.0f, 0.0f};
         if (warm.man_prev) {
-            const uint32_t pm = warm.man_prev[m];
+            const uint32_t pm = __float_as_uint(r1.w);  // index of the pair's manifold in the previous update (narrow phase)
             if (pm != 0xFFFFFFFFu) {
                 const float4* prec = reinterpret_cast<const float4*>(warm.geo_prev) + 8 * (size_t)pm;
                 const float4* pimp = reinterpret_cast<const float4*>(warm.imp_prev) + 3 * (size_t)pm;
@@ -128,11 +128,13 @@ __global__ __launch_bounds__(256) void k_rows_build(StepCounters* __restrict__ c
         }
         // persistent colouring: a manifold that is new in this update enters the colour table (kernels.hpp)
         if (table.tab && (table.all || __float_as_uint(r0.w) == 0u)) color_table_insert(table, a, b, m, ctr);
+        // a kept colour came with the record; a new manifold's was made by the colouring rounds since
+        const uint32_t color_m = __float_as_uint(r0.w) != 0u ? __float_as_uint(r0.w) - 1u : man_color[m];
         uint32_t ticket = 0;
         if (flow) {
             // the colours in use at a body are exactly the colours of its manifolds (all distinct), so the rank of
             // this row among the body's manifolds in solve order = number of its colours below this one
-            const unsigned long long below = (1ull << man_color[m]) - 1ull;
+            const unsigned long long below = (1ull << color_m) - 1ull;
             const unsigned long long ua = used[a];
             ticket = (uint32_t)__popcll(ua & below) | ((uint32_t)__popcll(ua) << 8);
             if (has_b) {
@@ -149,7 +151,7 @@ __global__ __launch_bounds__(256) void k_rows_build(StepCounters* __restrict__ c
             // tag is current, granules otherwise); 2 another cluster's body (granules only); 3 no body (ground).
             // publish: the body's NEXT update in solve order (next colour in use at the body, cyclically) belongs to a
             // remote row, so this update must be written to the granules for it
-            const unsigned long long bitc = 1ull << man_color[m];
+            const unsigned long long bitc = 1ull << color_m;
             const uint32_t ha = cluster_home(cluster_slot, a, cluster_slots);
             const uint32_t hb = has_b ? cluster_home(cluster_slot, b, cluster_slots) : kNoHome;
             const uint32_t owner = cluster_row_owner(a, ha, hb, cluster_count);
