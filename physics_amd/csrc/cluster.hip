@@ -258,9 +258,13 @@ __global__ __launch_bounds__(256) void k_cluster_keys(uint64_t max_manifolds, co
         if (hb != kNoHome && hb != owner) atomicOr(&body_shared[2 * (size_t)b + (c >> 5)], 1u << (c & 31u));
     }
     __syncthreads();
-    if (threadIdx.x < PHYS_MAX_COLORS && s_hist[threadIdx.x]) {
-        atomicAdd(&ctr->color_count[threadIdx.x], s_hist[threadIdx.x]);
-        atomicMax(&ctr->n_colors, threadIdx.x + 1u);
+    // (PHYS_MAX_COLORS == 64: one wave) ONE atomicMax per workgroup - every lane with a count doing its own was up to 64
+    // same-address atomics per workgroup, 2048 workgroups
+    if (threadIdx.x < PHYS_MAX_COLORS) {
+        const uint32_t cnt = s_hist[threadIdx.x];
+        if (cnt) atomicAdd(&ctr->color_count[threadIdx.x], cnt);
+        const unsigned long long live = __ballot(cnt != 0u);
+        if (threadIdx.x == 0 && live) atomicMax(&ctr->n_colors, 64u - (uint32_t)__clzll((long long)live));
     }
 }
 
