@@ -792,13 +792,14 @@ void launch_narrowphase(phys_world* w) {
     do {                                                                                                               \
         uint64_t blocks = (work + T * kItems - 1) / (T * kItems);                                                      \
         if (blocks > 256 * 16) blocks = 256 * 16;                                                                      \
-        hipLaunchKernelGGL((k_narrowphase<T, kItems>), dim3((unsigned)blocks), dim3(T), 0, w->stream, n_ground, n_owned, w->pairs.p, \
+        hipLaunchKernelGGL((k_narrowphase<T, kItems>), dim3((unsigned)blocks), dim3(T), np_extra_lds, w->stream, n_ground, n_owned, w->pairs.p, \
                            w->max_pairs, w->geo.p, w->cfg.contact_margin, \
                            w->cfg.ground_height, w->max_manifolds, w->man_a.p, w->man_b.p,                             \
                            w->man_color.p, w->man_geo.p, w->man_prio.p, w->color_state.p,                              \
                            w->color_state.p + n, reinterpret_cast<ulonglong2*>(w->ctab.p), cache_mask, early_probe, stamp, \
                            w->unc_list.p, w->warm ? w->man_prev.p : nullptr, w->man_imp.p, w->counters.p);             \
     } while (0)
+    static const unsigned np_extra_lds = getenv("PHYS_DEBUG_NP_EXTRA_LDS") ? (unsigned)atoi(getenv("PHYS_DEBUG_NP_EXTRA_LDS")) : 0u;  // occupancy experiments
     static const int np_threads_env = getenv("PHYS_DEBUG_NP_THREADS") ? atoi(getenv("PHYS_DEBUG_NP_THREADS")) : 0;  // measurements
     // 128 threads only while the whole stage is a few workgroups (C2: 10k manifolds); measured at 230k manifolds (C3):
     // 0.175 ms with 128 threads, 0.133 with 256; at 2.9M (C5): 0.86 vs 0.55, and 512 no better than 256
