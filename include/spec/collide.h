@@ -39,16 +39,15 @@ typedef struct {
     float depth[4];
 } manifold_t;
 
-/* per-lane scratch of the polygon clipper: 192 bytes. The HIP narrow phase keeps it in LDS (one slice per
- * lane, odd dword stride) instead of private scratch memory; the oracle puts it on the stack. The depths of the
- * candidate points live in polyB, which is free by the time they are made (candidates are compacted in place in
- * polyA): at 49 dwords per lane three 256-thread workgroups fit a CU's LDS instead of two, and the narrow phase is
- * bound by how many dependent memory round trips its few resident waves can overlap. */
+/* per-lane scratch of the polygon clipper: 128 bytes - ONE polygon of up to 8 vertices, clipped in place (clip_poly), and
+ * the depths of the candidate points. The HIP narrow phase keeps it in LDS (one slice per lane, odd dword stride)
+ * instead of private scratch memory; the oracle puts it on the stack. At 33 dwords per lane four 256-thread workgroups
+ * fit a CU's LDS (two at 192 bytes and two polygons, three at 48 dwords): the narrow phase is bound by how many dependent
+ * memory round trips its resident waves can overlap. */
 typedef struct {
-    v3 polyA[8];
-    v3 polyB[8];
+    v3 poly[8];
+    float depth[8];
 } clip_ws_t;
-PHYS_HD float* clip_ws_depths(clip_ws_t* ws) { return &ws->polyB[0].x; }
 
 PHYS_HD geom_t geom_make(v3 c, quat q, v3 h, uint32_t type) {
     geom_t g;
@@ -162,25 +161,35 @@ PHYS_HD void collide_sphere_box_raw(const geom_t* S, const geom_t* X, float marg
     m->depth[0] = depth;
 }
 
-/* Sutherland-Hodgman clip of a convex polygon (<= 8 verts) against  dot(p - c, u) <= lim */
-PHYS_HD int clip_poly(const v3* in, int n_in, v3 c, v3 u, float lim, v3* out) {
+/* Sutherland-Hodgman clip of a convex polygon (<= 8 verts) against  dot(p - c, u) <= lim, IN PLACE. Vertex k is the
+ * `a` of edge k and the `b` of edge k - 1: it travels in registers from one edge to the next, and so does its distance (the
+ * same expression on the same vertex: the same value), and the first vertex, which the last edge needs again. The output
+ * never passes the vertex that is read next: before edge k at most k points are out - or k + 1 right behind a LEAVING edge
+ * (two points out for one vertex in), whose next vertex is outside and puts out at most one. A convex polygon leaves a
+ * half-plane once; should rounding ever make a degenerate one leave twice, a vertex is overwritten before it is read -
+ * deterministically, inside the array, and alike in the oracle and on the device. */
+PHYS_HD int clip_poly(v3* p, int n_in, v3 c, v3 u, float lim) {
     int n_out = 0;
+    if (n_in <= 0) return 0;
+    const v3 first = p[0];
+    v3 a = first;
+    float da = v3_dot(v3_sub(a, c), u) - lim;
     for (int k = 0; k < 8; ++k) {
         if (k >= n_in) break;
-        const v3 a = in[k];
-        const v3 b = in[(k + 1 == n_in) ? 0 : k + 1];
-        const float da = v3_dot(v3_sub(a, c), u) - lim;
+        v3 b = first;
+        if (k + 1 != n_in) b = p[k + 1];
         const float db = v3_dot(v3_sub(b, c), u) - lim;
         if (da <= 0.0f) {
-            if (n_out < 8) out[n_out++] = a;
+            if (n_out < 8) p[n_out++] = a;
             if (db > 0.0f) {
                 const float t = da / (da - db);
-                if (n_out < 8) out[n_out++] = v3_add(a, v3_scale(v3_sub(b, a), t));
+                if (n_out < 8) p[n_out++] = v3_add(a, v3_scale(v3_sub(b, a), t));
             }
         } else if (db <= 0.0f) {
             const float t = da / (da - db);
-            if (n_out < 8) out[n_out++] = v3_add(a, v3_scale(v3_sub(b, a), t));
+            if (n_out < 8) p[n_out++] = v3_add(a, v3_scale(v3_sub(b, a), t));
         }
+        a = b; da = db;
     }
     return n_out;
 }
@@ -237,8 +246,7 @@ PHYS_HD void box_face_contact(const geom_t* Ref, const geom_t* Inc, int r, float
     const v3 fc = v3_add(Inc->c, v3_scale(m33_col(&Inc->R, j), jsgn * v3_get(Inc->h, j)));
     const v3 e1 = v3_scale(m33_col(&Inc->R, j1), v3_get(Inc->h, j1));
     const v3 e2 = v3_scale(m33_col(&Inc->R, j2), v3_get(Inc->h, j2));
-    v3* polyA = ws->polyA;
-    v3* polyB = ws->polyB;
+    v3* polyA = ws->poly;
     polyA[0] = v3_add(v3_add(fc, e1), e2);
     polyA[1] = v3_add(v3_sub(fc, e1), e2);
     polyA[2] = v3_sub(v3_sub(fc, e1), e2);
@@ -247,15 +255,15 @@ PHYS_HD void box_face_contact(const geom_t* Ref, const geom_t* Inc, int r, float
     const int r1 = (r + 1) % 3, r2 = (r + 2) % 3;
     const v3 u1 = m33_col(&Ref->R, r1), u2 = m33_col(&Ref->R, r2);
     const float l1 = v3_get(Ref->h, r1), l2 = v3_get(Ref->h, r2);
-    n = clip_poly(polyA, n, Ref->c, u1, l1, polyB);
-    n = clip_poly(polyB, n, Ref->c, v3_neg(u1), l1, polyA);
-    n = clip_poly(polyA, n, Ref->c, u2, l2, polyB);
-    n = clip_poly(polyB, n, Ref->c, v3_neg(u2), l2, polyA);
+    n = clip_poly(polyA, n, Ref->c, u1, l1);
+    n = clip_poly(polyA, n, Ref->c, v3_neg(u1), l1);
+    n = clip_poly(polyA, n, Ref->c, u2, l2);
+    n = clip_poly(polyA, n, Ref->c, v3_neg(u2), l2);
     /* extent of the contact patch (the incident face inside the reference face's side planes) along the two
      * in-plane axes of the reference face: the sliver rule below */
     float lo1 = 3.0e38f, hi1 = -3.0e38f, lo2 = 3.0e38f, hi2 = -3.0e38f;
-    /* keep points at or below the reference face (+ margin): compacted in place (nc <= k), depths into the free polyB */
-    v3* cand = ws->polyA; float* cdep = clip_ws_depths(ws); int nc = 0;
+    /* keep points at or below the reference face (+ margin): compacted in place (nc <= k) */
+    v3* cand = ws->poly; float* cdep = ws->depth; int nc = 0;
     const float hr = v3_get(Ref->h, r);
     float deepest = -3.0e38f;
     for (int k = 0; k < 8; ++k) {
@@ -423,7 +431,7 @@ PHYS_HD void collide_ground(const geom_t* A, float ground, float margin, manifol
         m->pt[0] = v3_make(A->c.x, bottom + 0.5f * depth, A->c.z);
         m->depth[0] = depth;
     } else if (A->type == PHYS_SPEC_SHAPE_BOX) {
-        v3* cand = ws->polyA; float* cdep = clip_ws_depths(ws); int nc = 0;
+        v3* cand = ws->poly; float* cdep = ws->depth; int nc = 0;
         const v3 ex = v3_scale(m33_col(&A->R, 0), A->h.x);
         const v3 ey = v3_scale(m33_col(&A->R, 1), A->h.y);
         const v3 ez = v3_scale(m33_col(&A->R, 2), A->h.z);

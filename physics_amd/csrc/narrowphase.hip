@@ -54,7 +54,7 @@ __global__ __launch_bounds__(kNpThreads) void k_narrowphase(
     // another still reads this trip's to place its manifolds - there is no barrier at the end of a trip any more
     __shared__ uint32_t wtot[2][4][kNpThreads / 64];
     __shared__ uint32_t block_base, unc_base;
-    // polygon-clipper scratch in LDS: one 56-dword slice per lane at an odd (57) dword stride, so the lanes of
+    // polygon-clipper scratch in LDS: one 32-dword slice per lane at an odd (33) dword stride, so the lanes of
     // a wave hit distinct banks; private scratch memory would go through L1/L2 instead
     constexpr int kWsStride = sizeof(clip_ws_t) / 4 + 1;
     __shared__ float ws_lds[kNpThreads * kWsStride];
@@ -805,8 +805,17 @@ void launch_narrowphase(phys_world* w) {
     // 0.175 ms with 128 threads, 0.133 with 256; at 2.9M (C5): 0.86 vs 0.55, and 512 no better than 256
     const bool few = w->hint.valid ? w->hint.n_manifolds <= 32768u : n <= 200000u;
     static const int np_items_env = getenv("PHYS_DEBUG_NP_ITEMS") ? atoi(getenv("PHYS_DEBUG_NP_ITEMS")) : 0;  // measurements
+    // one or two work items per lane and trip: one (118 registers: four workgroups per CU, which the in-place clipper's LDS
+    // slice admits) where 30 % or more of the work items (ground tests + candidate pairs) become manifolds - clipping and
+    // the stores of a manifold are most of a trip, resident waves hide them; two (151 registers: three workgroups per CU)
+    // where most items are rejected early and the chain behind the test - ballots, barriers, reservation - is most of a trip.
+    // Measured (ms, one / two): settled 1M pile (33 % become manifolds) 0.819 / 0.917, C3 (41 %) 0.091 / 0.093, 1M cubes in
+    // mid-fall (28 %: a million ground tests that the AABB rules out) 0.081 / 0.067, C5 (23 %) 0.251 / 0.230. From the counts of
+    // an earlier update, like every launch choice.
+    const bool one_item = np_items_env ? np_items_env == 1
+                                       : (w->hint.valid && 10ull * w->hint.n_manifolds >= 3ull * ((uint64_t)n_ground + w->hint.n_pairs));
     if (np_threads_env ? np_threads_env == 128 : few) PHYS_NP_LAUNCH(128, 1);
-    else if (np_items_env == 1) PHYS_NP_LAUNCH(256, 1);
+    else if (one_item) PHYS_NP_LAUNCH(256, 1);
     else PHYS_NP_LAUNCH(256, 2);
 #undef PHYS_NP_LAUNCH
 }
