@@ -802,21 +802,24 @@ void launch_narrowphase(phys_world* w) {
     static const unsigned np_extra_lds = getenv("PHYS_DEBUG_NP_EXTRA_LDS") ? (unsigned)atoi(getenv("PHYS_DEBUG_NP_EXTRA_LDS")) : 0u;  // occupancy experiments
     static const int np_threads_env = getenv("PHYS_DEBUG_NP_THREADS") ? atoi(getenv("PHYS_DEBUG_NP_THREADS")) : 0;  // measurements
     // 128 threads only while the whole stage is a few workgroups (C2: 10k manifolds); measured at 230k manifolds (C3):
-    // 0.175 ms with 128 threads, 0.133 with 256; at 2.9M (C5): 0.86 vs 0.55, and 512 no better than 256
+    // 0.175 ms with 128 threads, 0.133 with 256; at 2.9M (C5): 0.86 vs 0.55 (round 2)
     const bool few = w->hint.valid ? w->hint.n_manifolds <= 32768u : n <= 200000u;
     static const int np_items_env = getenv("PHYS_DEBUG_NP_ITEMS") ? atoi(getenv("PHYS_DEBUG_NP_ITEMS")) : 0;  // measurements
-    // one or two work items per lane and trip: one (118 registers: four workgroups per CU, which the in-place clipper's LDS
-    // slice admits) where 30 % or more of the work items (ground tests + candidate pairs) become manifolds - clipping and
-    // the stores of a manifold are most of a trip, resident waves hide them; two (151 registers: three workgroups per CU)
-    // where most items are rejected early and the chain behind the test - ballots, barriers, reservation - is most of a trip.
-    // Measured (ms, one / two): settled 1M pile (33 % become manifolds) 0.819 / 0.917, C3 (41 %) 0.091 / 0.093, 1M cubes in
-    // mid-fall (28 %: a million ground tests that the AABB rules out) 0.081 / 0.067, C5 (23 %) 0.251 / 0.230. From the counts of
-    // an earlier update, like every launch choice.
-    const bool one_item = np_items_env ? np_items_env == 1
-                                       : (w->hint.valid && 10ull * w->hint.n_manifolds >= 3ull * ((uint64_t)n_ground + w->hint.n_pairs));
-    if (np_threads_env ? np_threads_env == 128 : few) PHYS_NP_LAUNCH(128, 1);
-    else if (one_item) PHYS_NP_LAUNCH(256, 1);
-    else PHYS_NP_LAUNCH(256, 2);
+    // Workgroup shape (all variants: same manifolds, emission order is arbitrary anyway). A trip ends in one reservation
+    // behind two barriers, and the waves a CU holds are what hides a trip's round trips from each other; the in-place
+    // clipper's LDS slice (33 dwords per lane) admits 16 waves per CU at 118 registers. Measured, ms per update
+    // (C5 / 1M cubes in mid-fall / settled 1M pile / C3):
+    //   256 threads, one item per lane (4 workgroups per CU)            0.251 / 0.081 / 0.812 / 0.091
+    //   256 threads, two items per lane (151 registers: 12 waves)       0.230 / 0.067 / 0.917 / 0.093
+    //   512 threads, one item (2 workgroups per CU, half the atomics)   0.206 / 0.069 / 0.836 / 0.075   <- the default
+    //   1024 threads, one item (a barrier over 16 waves)                0.231 / 0.084 / 0.937 / 0.080
+    // PHYS_DEBUG_NP_THREADS=128|256|512|1024 and PHYS_DEBUG_NP_ITEMS=1|2 (with 256) pick one by hand.
+    const int threads = np_threads_env ? np_threads_env : (few ? 128 : 512);
+    if (threads == 128) PHYS_NP_LAUNCH(128, 1);
+    else if (threads == 256 && np_items_env == 2) PHYS_NP_LAUNCH(256, 2);
+    else if (threads == 256) PHYS_NP_LAUNCH(256, 1);
+    else if (threads == 1024) PHYS_NP_LAUNCH(1024, 1);
+    else PHYS_NP_LAUNCH(512, 1);
 #undef PHYS_NP_LAUNCH
 }
 
