@@ -231,6 +231,8 @@ __global__ __launch_bounds__(256) void k_cluster_homes(uint32_t n, uint32_t n_ow
 }
 
 // ---- per step: rows sorted by (owner cluster, colour); bodies touched by a row of another cluster ----------
+constexpr int kKeysItems = 4;        // manifolds per lane and trip
+constexpr int kKeysSlots = 2048;     // LDS table of the (cluster, colour) keys of one trip (<= 1024 of them)
 __global__ __launch_bounds__(256) void k_cluster_keys(uint64_t max_manifolds, const uint32_t* __restrict__ man_a,
                                                       const uint32_t* __restrict__ man_b, const uint32_t* __restrict__ man_color,
                                                       const uint32_t* __restrict__ cluster_slot, uint32_t slots, uint32_t clusters,
@@ -239,27 +241,58 @@ __global__ __launch_bounds__(256) void k_cluster_keys(uint64_t max_manifolds, co
     // manifolds per colour and the number of colours ride along (a cluster step has no use for the colour-major sort
     // that k_color_hist / k_color_offsets serve, only for these counters): one LDS histogram per workgroup
     __shared__ uint32_t s_hist[PHYS_MAX_COLORS];
+    // The rank of a manifold inside its (owner cluster, colour) segment is an arrival order nothing depends on, so it need
+    // not come from one returning global atomic per manifold (C5: 755k of them, 41 us): the manifolds of a trip are
+    // neighbours in space and share a few dozen keys, which are counted in an LDS table first; one global atomic per key
+    // and trip then reserves the whole count.
+    __shared__ uint32_t t_key[kKeysSlots], t_cnt[kKeysSlots], t_base[kKeysSlots];
     if (threadIdx.x < PHYS_MAX_COLORS) s_hist[threadIdx.x] = 0u;
-    __syncthreads();
     const uint32_t raw = ctr->n_manifolds;
     const uint32_t M = (uint64_t)raw < max_manifolds ? raw : (uint32_t)max_manifolds;
-    for (uint32_t m = blockIdx.x * blockDim.x + threadIdx.x; m < M; m += gridDim.x * blockDim.x) {
-        const uint32_t a = man_a[m], b = man_b[m], c = man_color[m];
-        if (c >= (uint32_t)PHYS_MAX_COLORS) { man_rank[m] = 0xFFFFFFFFu; continue; }
-        atomicAdd(&s_hist[c], 1u);
-        const uint32_t ha = cluster_home(cluster_slot, a, slots);
-        const uint32_t hb = b == PHYS_GROUND_ID ? kNoHome : cluster_home(cluster_slot, b, slots);
-        const uint32_t owner = cluster_row_owner(a, ha, hb, clusters);
-        // arrival order inside a (cluster, colour) segment: nothing depends on it (rows of one colour share no body)
-        man_rank[m] = atomicAdd(&seg_count[owner * PHYS_MAX_COLORS + c], 1u);
-        // a body with a home receives updates from ANOTHER workgroup exactly in the rows that its home does not own:
-        // that body is `shared`, and the colours of those rows are its remote colours (two halves of a 64-bit mask).
-        // (A's home owns the row whenever A has one.)
-        if (hb != kNoHome && hb != owner) atomicOr(&body_shared[2 * (size_t)b + (c >> 5)], 1u << (c & 31u));
+    constexpr uint32_t kTrip = 256u * kKeysItems;
+    for (uint64_t base = (uint64_t)blockIdx.x * kTrip; base < M; base += (uint64_t)gridDim.x * kTrip) {
+        for (uint32_t s = threadIdx.x; s < (uint32_t)kKeysSlots; s += 256u) { t_key[s] = 0xFFFFFFFFu; t_cnt[s] = 0u; }
+        __syncthreads();
+        uint32_t my_slot[kKeysItems], my_rank[kKeysItems];
+#pragma unroll
+        for (int j = 0; j < kKeysItems; ++j) {
+            const uint64_t m = base + (uint64_t)j * 256u + threadIdx.x;
+            my_slot[j] = 0xFFFFFFFFu; my_rank[j] = 0u;
+            if (m >= M) continue;
+            const uint32_t a = man_a[m], b = man_b[m], c = man_color[m];
+            if (c >= (uint32_t)PHYS_MAX_COLORS) continue;  // (man_rank[m] = ~0 below)
+            atomicAdd(&s_hist[c], 1u);
+            const uint32_t ha = cluster_home(cluster_slot, a, slots);
+            const uint32_t hb = b == PHYS_GROUND_ID ? kNoHome : cluster_home(cluster_slot, b, slots);
+            const uint32_t owner = cluster_row_owner(a, ha, hb, clusters);
+            const uint32_t key = owner * PHYS_MAX_COLORS + c;
+            uint32_t s = (key * 2654435761u) >> (32 - 11);  // 2048 slots, at most 1024 keys: the walk ends
+            for (;;) {
+                const uint32_t seen = atomicCAS(&t_key[s], 0xFFFFFFFFu, key);
+                if (seen == 0xFFFFFFFFu || seen == key) break;
+                s = (s + 1u) & (uint32_t)(kKeysSlots - 1);
+            }
+            my_slot[j] = s;
+            my_rank[j] = atomicAdd(&t_cnt[s], 1u);
+            // a body with a home receives updates from ANOTHER workgroup exactly in the rows that its home does not own:
+            // that body is `shared`, and the colours of those rows are its remote colours (two halves of a 64-bit mask).
+            // (A's home owns the row whenever A has one.)
+            if (hb != kNoHome && hb != owner) atomicOr(&body_shared[2 * (size_t)b + (c >> 5)], 1u << (c & 31u));
+        }
+        __syncthreads();
+        for (uint32_t s = threadIdx.x; s < (uint32_t)kKeysSlots; s += 256u)
+            if (t_cnt[s]) t_base[s] = atomicAdd(&seg_count[t_key[s]], t_cnt[s]);
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < kKeysItems; ++j) {
+            const uint64_t m = base + (uint64_t)j * 256u + threadIdx.x;
+            if (m < M) man_rank[m] = my_slot[j] == 0xFFFFFFFFu ? 0xFFFFFFFFu : t_base[my_slot[j]] + my_rank[j];
+        }
+        __syncthreads();  // the table is wiped at the top of the next trip
     }
     __syncthreads();
     // (PHYS_MAX_COLORS == 64: one wave) ONE atomicMax per workgroup - every lane with a count doing its own was up to 64
-    // same-address atomics per workgroup, 2048 workgroups
+    // same-address atomics per workgroup
     if (threadIdx.x < PHYS_MAX_COLORS) {
         const uint32_t cnt = s_hist[threadIdx.x];
         if (cnt) atomicAdd(&ctr->color_count[threadIdx.x], cnt);
@@ -313,7 +346,10 @@ void launch_cluster_sort(phys_world* w, unsigned blocks) {
     const bool self_zeroing = scan_is_one_launch(bins);
     if (!self_zeroing) (void)hipMemsetAsync(w->seg_count.p, 0, (size_t)bins * 4, s);
     (void)hipMemsetAsync(w->body_shared.p, 0, (size_t)w->n * 8, s);
-    hipLaunchKernelGGL(k_cluster_keys, dim3(blocks), dim3(256), 0, s, w->max_manifolds, w->man_a.p, w->man_b.p, w->man_color.p,
+    // (a trip of k_cluster_keys is 1024 manifolds: as many workgroups as the last known count needs, any number is correct)
+    const uint64_t key_trips = w->hint.valid ? ((uint64_t)w->hint.n_manifolds * 5 / 4) / (256u * kKeysItems) + 1 : blocks;
+    const unsigned key_blocks = (unsigned)std::min<uint64_t>(blocks, std::max<uint64_t>(1, key_trips));
+    hipLaunchKernelGGL(k_cluster_keys, dim3(key_blocks), dim3(256), 0, s, w->max_manifolds, w->man_a.p, w->man_b.p, w->man_color.p,
                        w->cluster_slot.p, w->cluster_slots, w->cluster_count, w->seg_count.p, w->man_rank.p, w->body_shared.p, w->counters.p);
     launch_exclusive_scan(w, w->seg_count.p, bins, w->seg_start.p, self_zeroing);
     hipLaunchKernelGGL(k_cluster_place, dim3(blocks), dim3(256), 0, s, w->max_manifolds, w->man_a.p, w->man_b.p, w->man_color.p,
