@@ -963,7 +963,11 @@ void launch_broadphase(phys_world* w) {
         const size_t dyn = (size_t)cap * 28;
         const size_t fixed = (kPairThreads / 64) * kBrickStagePerWave * 8 + kRegCells * 8 + 64;
         // persistent workgroups, as many as are resident at once (the LDS decides), never more than there are bricks
-        uint32_t per_cu = (uint32_t)std::min<size_t>(5, (160 * 1024) / (((dyn + fixed) + 1023) / 1024 * 1024));
+        // at most six per CU (74 registers: six waves per SIMD). Measured, us (C4 / 1M cubes in mid-fall / C5): 3 per CU 173 /
+        // 145 / 74, 4: 137 / 114 / 72, 5: 117 / 100 / 69, 6: 105 / 89 / 70; asked for 8 (not all resident: the late ones
+        // start on a drained chip) 131 / 109 / 69
+        static const size_t per_cu_max = getenv("PHYS_DEBUG_BRICK_PER_CU") ? (size_t)atoi(getenv("PHYS_DEBUG_BRICK_PER_CU")) : 6;  // measurements
+        uint32_t per_cu = (uint32_t)std::min<size_t>(per_cu_max, (160 * 1024) / (((dyn + fixed) + 1023) / 1024 * 1024));
         uint32_t wgs = 256u * std::max(per_cu, 1u);
         while (wgs > n_bricks) wgs >>= 1;
         static bool attr_set[64] = {};  // per device (function attributes are): more than 64 KiB of dynamic LDS needs it
