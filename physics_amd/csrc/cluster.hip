@@ -58,6 +58,9 @@ static uint32_t spread10(uint32_t x) {
     return x;
 }
 
+// the (cluster, colour) counters sit behind the 2 n mask words of body_shared, on a 16-byte boundary (the scans read uint4)
+static size_t seg_count_offset(uint64_t n) { return ((size_t)2 * n + 3) & ~(size_t)3; }
+
 int32_t cluster_assign(phys_world* w, const float* pos /* host, 3 * n_owned */) {
     w->cluster_count = 0;
     const uint64_t n = w->n, n_owned = w->n_owned;
@@ -100,9 +103,9 @@ int32_t cluster_assign(phys_world* w, const float* pos /* host, 3 * n_owned */) 
         const size_t homes_max = (size_t)cus * (kClusterLdsPerCu / kClusterSlotBytesDecl) + 64;
         PHYS_HIP_TRY(w->cluster_slot.resize(n));
         PHYS_HIP_TRY(w->cluster_body.resize(homes_max));
-        PHYS_HIP_TRY(w->body_shared.resize(2 * n));
-        PHYS_HIP_TRY(w->seg_count.resize((size_t)clusters_max * PHYS_MAX_COLORS + 4));
-        PHYS_HIP_TRY(hipMemsetAsync(w->seg_count.p, 0, ((size_t)clusters_max * PHYS_MAX_COLORS + 4) * 4, w->stream));
+        // (the per-(cluster, colour) counters live behind the bodies' masks: both are zeroed every update, by ONE memset)
+        PHYS_HIP_TRY(w->body_shared.resize(seg_count_offset(n) + (size_t)clusters_max * PHYS_MAX_COLORS + 4));
+        PHYS_HIP_TRY(hipMemsetAsync(w->body_shared.p, 0, (seg_count_offset(n) + (size_t)clusters_max * PHYS_MAX_COLORS + 4) * 4, w->stream));
         PHYS_HIP_TRY(w->seg_start.resize((size_t)clusters_max * PHYS_MAX_COLORS + 4));
         PHYS_HIP_TRY(w->man_rank.resize(w->max_manifolds));
         PHYS_HIP_TRY(w->active_flag.resize(n + 4));
@@ -140,9 +143,9 @@ int32_t cluster_assign(phys_world* w, const float* pos /* host, 3 * n_owned */) 
     }
     PHYS_HIP_TRY(w->cluster_slot.resize(n));
     PHYS_HIP_TRY(w->cluster_body.resize(body_of.size()));
-    PHYS_HIP_TRY(w->body_shared.resize(2 * n));  // 64-bit mask of remote colours per body
-    PHYS_HIP_TRY(w->seg_count.resize((size_t)clusters * PHYS_MAX_COLORS + 4));
-    PHYS_HIP_TRY(hipMemsetAsync(w->seg_count.p, 0, ((size_t)clusters * PHYS_MAX_COLORS + 4) * 4, w->stream));
+    // 64-bit mask of remote colours per body; behind them the per-(cluster, colour) counters (zeroed together: one memset)
+    PHYS_HIP_TRY(w->body_shared.resize(seg_count_offset(n) + (size_t)clusters * PHYS_MAX_COLORS + 4));
+    PHYS_HIP_TRY(hipMemsetAsync(w->body_shared.p, 0, (seg_count_offset(n) + (size_t)clusters * PHYS_MAX_COLORS + 4) * 4, w->stream));
     PHYS_HIP_TRY(w->seg_start.resize((size_t)clusters * PHYS_MAX_COLORS + 4));
     PHYS_HIP_TRY(w->man_rank.resize(w->max_manifolds));
     PHYS_HIP_TRY(hipMemcpyAsync(w->cluster_slot.p, cslot.data(), 4 * n, hipMemcpyHostToDevice, w->stream));
@@ -305,7 +308,9 @@ __global__ __launch_bounds__(256) void k_cluster_place(uint64_t max_manifolds, c
                                                        const uint32_t* __restrict__ man_b, const uint32_t* __restrict__ man_color,
                                                        const uint32_t* __restrict__ cluster_slot, uint32_t slots, uint32_t clusters,
                                                        const uint32_t* __restrict__ seg_start, const uint32_t* __restrict__ man_rank,
-                                                       uint32_t* __restrict__ row_src, const StepCounters* __restrict__ ctr) {
+                                                       uint32_t* __restrict__ row_src, const StepCounters* __restrict__ ctr,
+                                                       StepCounters* snap_out /* host-mapped, may be null */) {
+    counters_snapshot(ctr, snap_out);  // (k_cluster_keys made the last of them: colours and their counts)
     const uint32_t raw = ctr->n_manifolds;
     const uint32_t M = (uint64_t)raw < max_manifolds ? raw : (uint32_t)max_manifolds;
     for (uint32_t m = blockIdx.x * blockDim.x + threadIdx.x; m < M; m += gridDim.x * blockDim.x) {
@@ -320,7 +325,7 @@ __global__ __launch_bounds__(256) void k_cluster_place(uint64_t max_manifolds, c
 
 
 // called by launch_coloring in place of the colour-major placement
-void launch_cluster_sort(phys_world* w, unsigned blocks) {
+void launch_cluster_sort(phys_world* w, unsigned blocks, StepCounters* snap_out) {
     hipStream_t s = w->stream;
     const uint32_t bins = w->cluster_count * PHYS_MAX_COLORS;  // a multiple of 64
     PHYS_PROF(w, PHYS_STAGE_ROWS);
@@ -344,16 +349,16 @@ void launch_cluster_sort(phys_world* w, unsigned blocks) {
     // the per-(cluster, colour) counters: all zero on entry - at first use by the allocation's memset (cluster_assign), later
     // because the one-launch scan leaves them zeroed behind it (one memset launch less per update)
     const bool self_zeroing = scan_is_one_launch(bins);
-    if (!self_zeroing) (void)hipMemsetAsync(w->seg_count.p, 0, (size_t)bins * 4, s);
-    (void)hipMemsetAsync(w->body_shared.p, 0, (size_t)w->n * 8, s);
+    uint32_t* seg_count = w->body_shared.p + seg_count_offset(w->n);
+    (void)hipMemsetAsync(w->body_shared.p, 0, self_zeroing ? (size_t)w->n * 8 : (seg_count_offset(w->n) + (size_t)bins) * 4, s);
     // (a trip of k_cluster_keys is 1024 manifolds: as many workgroups as the last known count needs, any number is correct)
     const uint64_t key_trips = w->hint.valid ? ((uint64_t)w->hint.n_manifolds * 5 / 4) / (256u * kKeysItems) + 1 : blocks;
     const unsigned key_blocks = (unsigned)std::min<uint64_t>(blocks, std::max<uint64_t>(1, key_trips));
     hipLaunchKernelGGL(k_cluster_keys, dim3(key_blocks), dim3(256), 0, s, w->max_manifolds, w->man_a.p, w->man_b.p, w->man_color.p,
-                       w->cluster_slot.p, w->cluster_slots, w->cluster_count, w->seg_count.p, w->man_rank.p, w->body_shared.p, w->counters.p);
-    launch_exclusive_scan(w, w->seg_count.p, bins, w->seg_start.p, self_zeroing);
+                       w->cluster_slot.p, w->cluster_slots, w->cluster_count, seg_count, w->man_rank.p, w->body_shared.p, w->counters.p);
+    launch_exclusive_scan(w, seg_count, bins, w->seg_start.p, self_zeroing);
     hipLaunchKernelGGL(k_cluster_place, dim3(blocks), dim3(256), 0, s, w->max_manifolds, w->man_a.p, w->man_b.p, w->man_color.p,
-                       w->cluster_slot.p, w->cluster_slots, w->cluster_count, w->seg_start.p, w->man_rank.p, w->row_src.p, w->counters.p);
+                       w->cluster_slot.p, w->cluster_slots, w->cluster_count, w->seg_start.p, w->man_rank.p, w->row_src.p, w->counters.p, snap_out);
 }
 
 // ---- the solver ----------------------------------------------------------------------------------------------

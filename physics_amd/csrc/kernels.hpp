@@ -188,7 +188,18 @@ int32_t halo_pairs(phys_world* w, const void* dev_remote, uint64_t n_remote, uin
 
 // cluster.hip
 int32_t cluster_assign(phys_world* w, const float* host_pos);
-void launch_cluster_sort(phys_world* w, unsigned blocks);
+void launch_cluster_sort(phys_world* w, unsigned blocks, StepCounters* snap_out /* host-mapped slot for the counters, or null */);
+#ifdef __HIPCC__
+// the step counters copied out to a host-mapped slot by the first workgroup of a kernel that runs after their last writer
+__device__ __forceinline__ void counters_snapshot(const StepCounters* ctr, StepCounters* snap_out) {
+    if (snap_out && blockIdx.x == 0) {
+        constexpr uint32_t words = (uint32_t)(sizeof(StepCounters) / 4);
+        for (uint32_t k = threadIdx.x; k < words; k += blockDim.x)
+            reinterpret_cast<uint32_t*>(snap_out)[k] =
+                __hip_atomic_load(reinterpret_cast<const uint32_t*>(ctr) + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+#endif
 void launch_exclusive_scan(phys_world* w, uint32_t* in, uint32_t count, uint32_t* out, bool zero_in);  // broadphase.hip; count % 4 == 0
 bool scan_is_one_launch(uint32_t count);  // ... in which case zero_in leaves the counters zeroed behind the scan
 bool cluster_plan_dynamic(phys_world* w);  // cluster.hip: clusters / slots of this update from the hint (dynamic clusters)

@@ -591,9 +591,11 @@ __global__ __launch_bounds__(1024) void k_color_offsets(uint32_t* __restrict__ b
 
 __global__ __launch_bounds__(1024) void k_color_place(uint64_t max_manifolds, const uint32_t* __restrict__ man_color,
                                                       const uint32_t* __restrict__ block_off /*scanned block_hist*/, uint32_t nb,
-                                                      uint32_t* __restrict__ row_src, const StepCounters* __restrict__ ctr) {
+                                                      uint32_t* __restrict__ row_src, const StepCounters* __restrict__ ctr,
+                                                      StepCounters* snap_out /* host-mapped, may be null */) {
     __shared__ uint32_t cursor[PHYS_MAX_COLORS];
     if (threadIdx.x < PHYS_MAX_COLORS) cursor[threadIdx.x] = block_off[threadIdx.x * nb + blockIdx.x];
+    counters_snapshot(ctr, snap_out);
     __syncthreads();
     const uint32_t M = stored_manifolds(ctr, max_manifolds);
     for (uint32_t base = blockIdx.x * kSortChunk; base < M; base += gridDim.x * kSortChunk) {
@@ -912,13 +914,25 @@ void launch_coloring(phys_world* w) {
         nb = 1;
         while (nb < want && nb < (uint32_t)kSortBlocksMax) nb <<= 1;
     }
+    // the snapshot of the counters (launch-size hints of later updates) is written by the last kernel of the sort itself,
+    // into a host-mapped slot: the copy engine's turn between two kernels of the stream cost 4.4 us per update
+    StepCounters* d_snap = nullptr;
+    if (known) {
+        StepCounters* slot = snapshot_acquire(w);
+        if (slot && hipHostGetDevicePointer((void**)&d_snap, slot, 0) != hipSuccess) {
+            d_snap = nullptr;
+            (void)hipGetLastError();  // an answer handled here (the copy path takes over), not an error to leave behind
+        }
+    }
     if (w->cluster_step) {
-        launch_cluster_sort(w, blocks * (kColorThreads / 256));  // rows by (owner cluster, colour); counts the colours too
+        launch_cluster_sort(w, blocks * (kColorThreads / 256), d_snap);  // rows by (owner cluster, colour); counts the colours too
     } else {
     { PHYS_PROF(w, PHYS_STAGE_ROWS); hipLaunchKernelGGL(k_color_hist, dim3(nb), dim3(1024), 0, s, w->max_manifolds, w->man_color.p, w->color_block_hist.p, nb, w->counters.p); }
     { PHYS_PROF(w, PHYS_STAGE_ROWS); hipLaunchKernelGGL(k_color_offsets, dim3(1), dim3(1024), 0, s, w->color_block_hist.p, nb, w->counters.p); }
-    { PHYS_PROF(w, PHYS_STAGE_ROWS); hipLaunchKernelGGL(k_color_place, dim3(nb), dim3(1024), 0, s, w->max_manifolds, w->man_color.p, w->color_block_hist.p, nb, w->row_src.p, w->counters.p); }
+    // (n_colors and the per-colour counts are final here: k_color_place below may copy the counters out)
+    { PHYS_PROF(w, PHYS_STAGE_ROWS); hipLaunchKernelGGL(k_color_place, dim3(nb), dim3(1024), 0, s, w->max_manifolds, w->man_color.p, w->color_block_hist.p, nb, w->row_src.p, w->counters.p, d_snap); }
     }
+    if (d_snap) { snapshot_commit(w); snapshot_done = true; }
     }
     {
         // the new manifolds of this update go into the colour table in k_rows_build (launch_solver): one launch less
