@@ -192,6 +192,10 @@ bool cluster_plan_dynamic(phys_world* w) {
             // against 2.33 ms at 430k active bodies, 2.66 against 3.30 at 500k; with half the bodies homeless 3.61 against
             // 4.08) - fewer workgroups hide less of each other's colour steps. (A capacity set for tests is obeyed.)
             if ((!ok || per_cu < per_cu_max) && !w->cluster_cap_limit && !per_cu_env) return false;
+            // (PHYS_DEBUG_CLUSTERS_PER_CU asks for fewer, larger workgroups - never for homes that do not fit: with the
+            // switch set, the growing 1M-cube pile once ran one 160 KiB workgroup per CU with half its bodies homeless and
+            // ended in the hand-off time-out)
+            if (!ok && !w->cluster_cap_limit) return false;
             if (!ok) slots = kClusterMaxSlots / 64u * 64u;  // one workgroup per CU, as many homes as its LDS holds
             w->cluster_count = clusters;
             w->cluster_slots = slots;
