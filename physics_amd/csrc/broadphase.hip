@@ -426,7 +426,8 @@ __global__ __launch_bounds__(kPairThreads) void k_find_pairs(const uint32_t* __r
 // comes first in the half-shell order; own-cell pairs by id order).
 constexpr int kRegX = 6, kRegY = 6, kRegZ = 5, kRegCells = kRegX * kRegY * kRegZ;  // 180
 constexpr int kBrickLanesPerBody = 4;
-constexpr int kBrickStagePerWave = 256;  // pairs staged per wave (2 KiB)
+// pairs staged per wave: 256 (2 KiB) where a body has many pairs (C5: 12 - at 128 the flushes, one same-address atomic
+// each, made its search 0.244 ms instead of 0.069), 128 where it has few (C4: 1.3; a seventh workgroup per CU fits)
 
 // WHAT THE PAIR SEARCH WAITS FOR IS THE PAIR COUNTER. Same-address atomics serialise chip-wide at ~88 per microsecond, and
 // every flush of a stage is one: the one-lane-per-body kernel flushes once per wave (1M bodies: 15.6k flushes = 180 of
@@ -434,6 +435,7 @@ constexpr int kBrickStagePerWave = 256;  // pairs staged per wave (2 KiB)
 // are PERSISTENT - a few per CU, each working through many bricks - and keep their hits in LDS across bricks; between two
 // bricks, once half the stage is full, the four waves' hits go out behind ONE atomic (C4: ~2.5k atomics for 1.3M pairs).
 // A wave whose own part fills up inside a brick (dense scenes) still flushes on its own.
+template <int kBrickStagePerWave>
 __device__ __forceinline__ void workgroup_flush(PairStage& st, uint32_t* s_cnt, uint32_t* s_base, uint32_t* __restrict__ pairs,
                                                 uint64_t max_pairs, StepCounters* __restrict__ ctr, bool force) {
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
@@ -461,7 +463,8 @@ __device__ __forceinline__ void workgroup_flush(PairStage& st, uint32_t* s_cnt, 
 
 // `cap` records fit the dynamic LDS of this launch (sized by the host from the largest region of an EARLIER update:
 // StepCounters::max_region; a brick with more than that walks global memory - slower, same pairs).
-__global__ __launch_bounds__(kPairThreads) void k_find_pairs_brick(const uint32_t* __restrict__ bucket_start, uint32_t n_bricks,
+template <int kBrickStagePerWave>
+__global__ __launch_bounds__(kPairThreads, 7) void k_find_pairs_brick(const uint32_t* __restrict__ bucket_start, uint32_t n_bricks,
                                                                    GridShape g, const uint32_t* __restrict__ sorted_ids,
                                                                    const float* __restrict__ sorted_box,
                                                                    uint32_t* __restrict__ pairs, uint64_t max_pairs,
@@ -613,9 +616,9 @@ __global__ __launch_bounds__(kPairThreads) void k_find_pairs_brick(const uint32_
             }
         }
         // the region tables and records are rewritten by the next brick: everybody is done with them behind the flush's barriers
-        workgroup_flush(st, s_cnt, &s_base, pairs, max_pairs, ctr, /*force=*/false);
+        workgroup_flush<kBrickStagePerWave>(st, s_cnt, &s_base, pairs, max_pairs, ctr, /*force=*/false);
     }
-    workgroup_flush(st, s_cnt, &s_base, pairs, max_pairs, ctr, /*force=*/true);
+    workgroup_flush<kBrickStagePerWave>(st, s_cnt, &s_base, pairs, max_pairs, ctr, /*force=*/true);
     // the largest region met: what a later update sizes its stage by (only a raise is an atomic)
     if (threadIdx.x == 0 && seen_max > ctr->max_region) atomicMax(&ctr->max_region, seen_max);
 }
@@ -961,24 +964,32 @@ void launch_broadphase(phys_world* w) {
         uint32_t cap = w->hint.valid && w->hint.max_region ? w->hint.max_region + w->hint.max_region / 4 : 1024u;
         cap = std::min(std::max((cap + 63u) & ~63u, 256u), kCapMax);
         const size_t dyn = (size_t)cap * 28;
-        const size_t fixed = (kPairThreads / 64) * kBrickStagePerWave * 8 + kRegCells * 8 + 64;
+        // few pairs per body (of an earlier update): the small stage, which leaves room for a seventh workgroup per CU
+        static const int stage_env = getenv("PHYS_DEBUG_BRICK_STAGE") ? atoi(getenv("PHYS_DEBUG_BRICK_STAGE")) : 0;  // measurements: 128 | 256
+        const bool small_stage = stage_env ? stage_env == 128 : (w->hint.valid && (uint64_t)w->hint.n_pairs < 3ull * w->n);
+        const size_t fixed = (kPairThreads / 64) * (small_stage ? 128 : 256) * 8 + kRegCells * 8 + 64;
         // persistent workgroups, as many as are resident at once (the LDS decides), never more than there are bricks
-        // at most six per CU (74 registers: six waves per SIMD). Measured, us (C4 / 1M cubes in mid-fall / C5): 3 per CU 173 /
-        // 145 / 74, 4: 137 / 114 / 72, 5: 117 / 100 / 69, 6: 105 / 89 / 70; asked for 8 (not all resident: the late ones
-        // start on a drained chip) 131 / 109 / 69
-        static const size_t per_cu_max = getenv("PHYS_DEBUG_BRICK_PER_CU") ? (size_t)atoi(getenv("PHYS_DEBUG_BRICK_PER_CU")) : 6;  // measurements
+        // at most seven per CU (66 registers: seven waves per SIMD). Measured, us (C4 / 1M cubes in mid-fall / C5): 3 per CU
+        // 173 / 145 / 74, 4: 137 / 114 / 72, 5: 117 / 100 / 69, 6: 105 / 89 / 70, 7 (small stage): 103 / 83 / -; asked for 8
+        // (not all resident: the late ones start on a drained chip) 131 / 109 / 69
+        static const size_t per_cu_max = getenv("PHYS_DEBUG_BRICK_PER_CU") ? (size_t)atoi(getenv("PHYS_DEBUG_BRICK_PER_CU")) : 7;  // measurements
         uint32_t per_cu = (uint32_t)std::min<size_t>(per_cu_max, (160 * 1024) / (((dyn + fixed) + 1023) / 1024 * 1024));
         uint32_t wgs = 256u * std::max(per_cu, 1u);
         while (wgs > n_bricks) wgs >>= 1;
         static bool attr_set[64] = {};  // per device (function attributes are): more than 64 KiB of dynamic LDS needs it
         if (!attr_set[w->device & 63]) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_find_pairs_brick), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) == hipSuccess)
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_find_pairs_brick<128>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) == hipSuccess &&
+                hipFuncSetAttribute(reinterpret_cast<const void*>(&k_find_pairs_brick<256>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) == hipSuccess)
                 attr_set[w->device & 63] = true;
             else (void)hipGetLastError();
         }
         PHYS_PROF(w, PHYS_STAGE_PAIRS);
-        hipLaunchKernelGGL(k_find_pairs_brick, dim3(wgs), dim3(kPairThreads), dyn, s, w->bucket_start.p, n_bricks, axis_mask,
-                           w->sorted_ids.p, w->sorted_box.p, w->pairs.p, w->max_pairs, w->counters.p, cap);
+        if (small_stage)
+            hipLaunchKernelGGL(k_find_pairs_brick<128>, dim3(wgs), dim3(kPairThreads), dyn, s, w->bucket_start.p, n_bricks, axis_mask,
+                               w->sorted_ids.p, w->sorted_box.p, w->pairs.p, w->max_pairs, w->counters.p, cap);
+        else
+            hipLaunchKernelGGL(k_find_pairs_brick<256>, dim3(wgs), dim3(kPairThreads), dyn, s, w->bucket_start.p, n_bricks, axis_mask,
+                               w->sorted_ids.p, w->sorted_box.p, w->pairs.p, w->max_pairs, w->counters.p, cap);
         return;
     }
     if (pair_lanes_env ? pair_lanes_env == 4 : n <= 65536u) {
