@@ -400,6 +400,10 @@ constexpr uint32_t kClusterSlotBytes = 64;  // LDS per body slot: {v, tag} {w, 1
 size_t cluster_lds_bytes(uint32_t slots) { return (size_t)slots * kClusterSlotBytes + (PHYS_MAX_COLORS + 1) * 4 + 12; }
 
 constexpr int kClusterThreads = 256;
+#ifndef PHYS_POLL_SLEEP
+#define PHYS_POLL_SLEEP 8
+#endif
+constexpr int kPollSleep = PHYS_POLL_SLEEP;
 template <bool DIAG, bool GUARDED>
 __global__ __launch_bounds__(kClusterThreads, DIAG ? kClusterPerCuDiag : kClusterPerCuFull) void k_solve_cluster(StepCounters* ctr, uint32_t iterations, uint32_t epoch,
                                                                   ClusterRowArrays rows, float friction,
@@ -640,7 +644,7 @@ __global__ __launch_bounds__(kClusterThreads, DIAG ? kClusterPerCuDiag : kCluste
                         }
                     }
                     if (needA || needB) {
-                        __builtin_amdgcn_s_sleep(8);
+                        __builtin_amdgcn_s_sleep(kPollSleep);
                         if ((++sweeps & 63u) == 0u) {
                             const bool gone = (wall_clock64() - t_start > timeout_ticks) ||
                                               (__hip_atomic_load(&ctr->overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 16u);
