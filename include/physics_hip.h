@@ -112,7 +112,7 @@ typedef struct phys_stats {
     uint32_t n_halo_records; /* records written by the last phys_halo_pack */
     uint64_t n_cross_pairs;  /* cross-rank pairs found by the last phys_halo_pairs */
     uint32_t n_ghosts;       /* ghost slots filled by the last phys_halo_unpack_ghosts */
-    uint32_t pad0;
+    uint32_t n_new_manifolds; /* manifolds of the last update whose pair had none in the update before (the colouring's work) */
 } phys_stats;
 
 /* reference defaults (see phys_config field comments) */

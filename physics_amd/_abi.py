@@ -71,7 +71,7 @@ class PhysStats(C.Structure):
         ("n_halo_records", C.c_uint32),
         ("n_cross_pairs", C.c_uint64),
         ("n_ghosts", C.c_uint32),
-        ("pad0", C.c_uint32),
+        ("n_new_manifolds", C.c_uint32),
     ]
 
 

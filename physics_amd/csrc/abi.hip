@@ -76,10 +76,15 @@ void poll_snapshots(phys_world* w) {
         if (w->snap_full[k]) {
             w->hint.full_rounds = c.color_rounds;
         } else {
+            w->hint.recent_new[w->hint.recent_pos % 8] = c.n_new_manifolds;
             w->hint.recent_rounds[w->hint.recent_pos++ % 8] = c.color_rounds;
-            uint32_t mx = 0;
-            for (int q = 0; q < 8; ++q) mx = w->hint.recent_rounds[q] > mx ? w->hint.recent_rounds[q] : mx;
+            uint32_t mx = 0, mn = 0;
+            for (int q = 0; q < 8; ++q) {
+                mx = w->hint.recent_rounds[q] > mx ? w->hint.recent_rounds[q] : mx;
+                mn = w->hint.recent_new[q] > mn ? w->hint.recent_new[q] : mn;
+            }
             w->hint.color_rounds = mx;
+            w->hint.n_new = mn;
         }
         for (int q = 0; q < kMaxColors; ++q) w->hint.color_count[q] = c.color_count[q];
     }
@@ -589,6 +594,7 @@ int32_t phys_get_stats(phys_world* w, phys_stats* out) {
     out->n_contacts = c.n_contacts;
     out->n_colors = c.n_colors;
     out->color_rounds = c.color_rounds;
+    out->n_new_manifolds = c.n_new_manifolds;
     if (w->cg_status.p && !w->constraints.empty()) {
         uint32_t st[2] = {1, 0};
         PHYS_HIP_TRY(hipMemcpy(st, w->cg_status.p, 8, hipMemcpyDeviceToHost));

@@ -275,7 +275,7 @@ __global__ __launch_bounds__(kNpThreads) void k_narrowphase(
     if (threadIdx.x == 0) {
         if (acc_pts) atomicAdd(&ctr->n_contacts, acc_pts);
         if (acc_ground) atomicAdd(&ctr->n_ground_manifolds, acc_ground);
-        if (acc_unc) atomicAdd(&ctr->n_uncolored, acc_unc);
+        if (acc_unc) { atomicAdd(&ctr->n_uncolored, acc_unc); atomicAdd(&ctr->n_new_manifolds, acc_unc); }
     }
 }
 

@@ -83,6 +83,7 @@ struct StepCounters {
     uint32_t n_active;       // owned bodies with at least one manifold in this update (dynamic clusters, cluster.hip)
     uint32_t n_used_buckets; // buckets of the sorted grid holding at least one body (k_cell_assign)
     uint32_t max_region;     // k_find_pairs_brick: most records in the region of one brick (sizes the LDS stage of later updates)
+    uint32_t n_new_manifolds;  // manifolds that kept no colour in this update (= the colouring's work; never counted down)
     uint32_t cluster_arrived[2][8];  // k_solve_cluster, per attempt: workgroups that have begun (eight counters: same-address
                                      // atomics serialise chip-wide) ...
     uint32_t cluster_state[2];       // ... and the launch's one decision: 0 undecided, 1 go (all are resident), 2 called off
@@ -161,6 +162,8 @@ struct StepHint {
     uint32_t full_rounds = 0;      // rounds of the last full re-colouring (0 = unknown)
     uint32_t recent_rounds[8] = {};
     uint32_t recent_pos = 0;
+    uint32_t n_new = 0xFFFFFFFFu;  // most manifolds without a kept colour in one of the recent incremental updates (~0: unknown)
+    uint32_t recent_new[8] = {};
     uint32_t color_count[kMaxColors] = {};
 };
 

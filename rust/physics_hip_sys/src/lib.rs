@@ -62,7 +62,7 @@ pub struct phys_stats {
     pub n_halo_records: u32,
     pub n_cross_pairs: u64,
     pub n_ghosts: u32,
-    pub pad0: u32,
+    pub n_new_manifolds: u32,
 }
 
 #[repr(C)]
