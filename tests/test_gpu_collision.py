@@ -145,6 +145,29 @@ def test_c2_10k_cubes_bit_exact():
     _run_scene(scenes.c2(), 150, 50)
 
 
+def test_new_manifolds_stat_counts_the_pairs_without_a_manifold_in_the_update_before():
+    """phys_stats.n_new_manifolds = manifolds of the last update whose pair had none in the update before (what the narrow
+    phase could keep no colour and no starting impulses for): checked against the manifold ids of consecutive updates, on
+    a pile that is still landing (hundreds of new contacts per update) and on a column at rest (none)."""
+    import physics_amd
+    from physics_amd import scenes
+    for sc, pre, lo in ((scenes.c3(10, 8, 10), 40, 10), (scenes.c5(2, 12, 2), 400, 0)):
+        w = physics_amd.World(sc.config())
+        sc.populate(w)
+        w.update_n(DT, pre)
+        prev = {tuple(p) for p in w.get_manifolds()[0].tolist()}
+        seen_new = 0
+        for _ in range(6):
+            w.update(DT)
+            ids = {tuple(p) for p in w.get_manifolds()[0].tolist()}
+            st = w.get_stats()
+            assert st.n_new_manifolds == len(ids - prev), (st.n_new_manifolds, len(ids - prev), len(ids))
+            seen_new += st.n_new_manifolds
+            prev = ids
+        assert seen_new >= lo
+        w.close()
+
+
 def test_tumbling_boxes_edge_contacts():
     """Rotated boxes with angular velocity dropped on each other: exercises the SAT edge axes,
     clipping and the reduction to 4 points."""
