@@ -174,7 +174,7 @@ class Rig:
     def make_world(self):
         import physics_amd
         # the bench has its GPU to itself (one rank per GPU, nothing else on it): PHYS_FLAG_EXCLUSIVE_GPU, stated in
-        # config.flags_note (the default - a guarded start of the cluster solver's launch - costs 0.06-0.09 ms per update)
+        # config.flags_note (the default - a guarded start of the cluster solver's launch - costs 0.04 ms per update)
         flags = self.scene.flags | (0 if self.rehearsal else physics_amd.FLAG_EXCLUSIVE_GPU)
         w = physics_amd.World(self.scene.config(device=self.local_rank, flags=flags))
         self.scene.populate(w)
@@ -573,7 +573,7 @@ def main():
                        "solver_iterations": rig.iters, "dt_nanos": DT_NANOS, "preroll_steps": preroll,
                        "flags_note": "PHYS_FLAG_EXCLUSIVE_GPU: nothing else runs on the benchmark's GPU, so the cluster solver "
                                      "skips the all-or-nothing count of its workgroups (the default, for hosts that share the "
-                                     "GPU with a renderer: +0.06-0.09 ms per update on C5 / the 1M cubes)",
+                                     "GPU with a renderer: +0.04 ms per update on C5 and on the 1M cubes: tools/guard_cost.py)",
                        "timed_window": f"steps {preroll + args.warmup}..{preroll + args.warmup + args.steps} of the trajectory",
                        "sharding": "none" if not sharded else (
                            f"x-slabs x{n_gpus}, one process per GPU; " +

@@ -57,7 +57,7 @@ extern "C" {
                                             application, no other process). The cluster solver - one launch whose
                                             workgroups must all be resident - by default starts all-or-nothing (every
                                             workgroup is counted in before anything is written; a launch that does not
-                                            fit beside other streams' kernels is called off and tried again: ~0.06-0.09
+                                            fit beside other streams' kernels is called off and tried again: ~0.04
                                             ms per update); with this flag it skips the count. A world that sets it on a
                                             GPU that IS shared may spin into the solver's 3 s time-out (PHYS_ERR_HIP at
                                             phys_sync). Several worlds of one process on a device are always guarded.

@@ -771,8 +771,8 @@ void launch_solve_cluster(phys_world* w, void* row_all, uint64_t cap, float fric
     struct Record { hipEvent_t e; hipStream_t s; ~Record() { if (e) (void)hipEventRecord(e, s); } } record{ev, w->stream};
     // ... and the all-or-nothing start inside the kernel covers what runs beside a launch from other streams - where that
     // can happen: ANYWHERE, unless the caller says the GPU is this world's alone (PHYS_FLAG_EXCLUSIVE_GPU: its own kernels
-    // run one after the other, every launch starts on an idle device, the count - C5: 0.09 ms, 1M cubes: 0.06 ms per
-    // update - is skipped). The guarded start is the default since round 3: a drop-in behind a render loop shares its GPU
+    // run one after the other, every launch starts on an idle device, the count - 0.04 ms per update on C5 and on the
+    // 1M cubes (tools/guard_cost.py) - is skipped). The guarded start is the default since round 3: a drop-in behind a render loop shares its GPU
     // with the renderer, and the unguarded launch's failure mode there is a 3 s spin.
     const bool guarded = worlds_on_device(w->device) > 1 || !(w->cfg.flags & PHYS_FLAG_EXCLUSIVE_GPU) || (w->cfg.flags & PHYS_FLAG_SHARED_GPU) != 0u;
     const uint32_t kAttempts = guarded ? 2u : 1u;
