@@ -63,6 +63,8 @@ static size_t seg_count_offset(uint64_t n) { return ((size_t)2 * n + 3) & ~(size
 
 int32_t cluster_assign(phys_world* w, const float* pos /* host, 3 * n_owned */) {
     w->cluster_count = 0;
+    w->seg_count_dirty = false;  // (both allocations below are zeroed)
+    w->seg_count_bins = 0;
     const uint64_t n = w->n, n_owned = w->n_owned;
     static const bool off = getenv("PHYS_DEBUG_NO_CLUSTER") != nullptr;
     w->cluster_dynamic = false;
@@ -352,15 +354,19 @@ void launch_cluster_sort(phys_world* w, unsigned blocks, StepCounters* snap_out)
     }
     // the per-(cluster, colour) counters: all zero on entry - at first use by the allocation's memset (cluster_assign), later
     // because the one-launch scan leaves them zeroed behind it (one memset launch less per update)
-    const bool self_zeroing = scan_is_one_launch(bins);
+    // (the three-launch scan of a larger table leaves its counters as they are: zeroed here then, and once more should a
+    // later update come with a table small enough to zero itself)
+    const bool self_zeroing = scan_is_one_launch(bins) && !w->seg_count_dirty;
+    w->seg_count_dirty = !scan_is_one_launch(bins);
     uint32_t* seg_count = w->body_shared.p + seg_count_offset(w->n);
-    (void)hipMemsetAsync(w->body_shared.p, 0, self_zeroing ? (size_t)w->n * 8 : (seg_count_offset(w->n) + (size_t)bins) * 4, s);
+    (void)hipMemsetAsync(w->body_shared.p, 0, self_zeroing ? (size_t)w->n * 8 : (seg_count_offset(w->n) + (size_t)std::max<uint32_t>(bins, w->seg_count_bins)) * 4, s);
+    w->seg_count_bins = bins;
     // (a trip of k_cluster_keys is 1024 manifolds: as many workgroups as the last known count needs, any number is correct)
     const uint64_t key_trips = w->hint.valid ? ((uint64_t)w->hint.n_manifolds * 5 / 4) / (256u * kKeysItems) + 1 : blocks;
     const unsigned key_blocks = (unsigned)std::min<uint64_t>(blocks, std::max<uint64_t>(1, key_trips));
     hipLaunchKernelGGL(k_cluster_keys, dim3(key_blocks), dim3(256), 0, s, w->max_manifolds, w->man_a.p, w->man_b.p, w->man_color.p,
                        w->cluster_slot.p, w->cluster_slots, w->cluster_count, seg_count, w->man_rank.p, w->body_shared.p, w->counters.p);
-    launch_exclusive_scan(w, seg_count, bins, w->seg_start.p, self_zeroing);
+    launch_exclusive_scan(w, seg_count, bins, w->seg_start.p, scan_is_one_launch(bins));
     hipLaunchKernelGGL(k_cluster_place, dim3(blocks), dim3(256), 0, s, w->max_manifolds, w->man_a.p, w->man_b.p, w->man_color.p,
                        w->cluster_slot.p, w->cluster_slots, w->cluster_count, w->seg_start.p, w->man_rank.p, w->row_src.p, w->counters.p, snap_out);
 }

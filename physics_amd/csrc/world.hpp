@@ -295,6 +295,8 @@ struct phys_world {
     phys::DevBuf<uint32_t> cluster_slot;   // body -> cluster * slots + slot
     phys::DevBuf<uint32_t> cluster_body;   // cluster * slots + slot -> body (0xFFFFFFFF: empty)
     phys::DevBuf<uint32_t> body_shared;    // 2 per body: 64-bit mask of the colours in which ANOTHER cluster's row updates it
+    bool seg_count_dirty = false;    // the (cluster, colour) counters were left non-zero by the last cluster step (three-launch scan)
+    uint32_t seg_count_bins = 0;     // ... which used this many of them
     phys::DevBuf<uint32_t> seg_count, seg_start;  // rows per (cluster, colour) - kept behind body_shared, seg_count itself is unused - and their exclusive scan
     phys::DevBuf<uint32_t> man_rank;       // manifold -> arrival rank inside its segment
     uint32_t flow_epoch = 0;         // solves since the buffers were cleared (upper half of every tag)
