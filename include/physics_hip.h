@@ -64,7 +64,7 @@ extern "C" {
                                             Same results either way. */
 #define PHYS_FLAG_SOLVER_CLUSTER 0x40u    /* contact solver: the cluster kernel (body velocities resident in LDS per spatial
                                             cluster, one launch) wherever the scene admits it (>= 32768 bodies, > 40k
-                                            manifolds), instead of only where it is the fastest path (>= 128k manifolds).
+                                            manifolds), instead of only where it is the fastest path (>= 170k manifolds).
                                             Bit-identical results; for tests and measurements */
 #define PHYS_FLAG_NO_WARM_START 0x100u   /* contact solver: start every update from zero impulses (rounds 1-2). Default: a manifold
                                             that persists starts from the impulses it ended the previous update with

@@ -442,7 +442,10 @@ __device__ __forceinline__ v3 granule_v3(u32x4 g) {
 
 constexpr long long kFlowTimeoutTicks = 300000000ll;  // 3 s of the 100 MHz wall clock (fault injection: 20 ms)
 constexpr uint64_t kFlowMaxManifolds = 400000;        // above: one launch per colour streams better
-constexpr uint64_t kFlowQuadMaxManifolds = 64000;     // below: four lanes per manifold (k_solve_flow_quad); 45k: +13 %, 108k: -32 %
+// below: four lanes per manifold (k_solve_flow_quad). Measured again with its statically dealt items (tools/cluster_crossover.py
+// --path flow, solve ms quad / one lane): towers 92k manifolds 0.371 / 0.466, 182k 0.645 / 0.670, 256k 0.914 / 0.903; mixed piles
+// 91k 0.308 / 0.405, 155k 0.444 / 0.502 (round 2, with tickets: 45k +13 %, 108k -32 %)
+constexpr uint64_t kFlowQuadMaxManifolds = 200000;
 
 // Work items are SOFTWARE-PIPELINED inside a workgroup: while item k waits for its bodies and is solved, the rows of
 // item k + 1 (its ticket is taken one item ahead) are already on their way, and so are - issued once those rows have
@@ -1175,7 +1178,8 @@ void launch_solver(phys_world* w, float dt) {
             return;
         }
         // about one wave per SIMD or less: waiting waves must not crowd out the ones that can run
-        const bool quad = m_hint <= kFlowQuadMaxManifolds;  // four lanes per manifold while the hop latency is everything
+        static const uint64_t quad_max_env = getenv("PHYS_DEBUG_FLOW_QUAD_MAX") ? strtoull(getenv("PHYS_DEBUG_FLOW_QUAD_MAX"), nullptr, 10) : 0;  // measurements
+        const bool quad = m_hint <= (quad_max_env ? quad_max_env : kFlowQuadMaxManifolds);  // four lanes per manifold while the hop latency is everything
         const uint32_t threads = 256u;
         const uint32_t rows_per_item = quad ? threads / 4 : threads;
         uint64_t items = (uint64_t)sweeps * ((m_hint * 5 / 4 + rows_per_item - 1) / rows_per_item) + 1;

@@ -19,10 +19,11 @@ constexpr int kMaxColors = 64;  // == PHYS_MAX_COLORS of include/spec/contact_so
 constexpr uint64_t kClusterMinBodies = 32768;  // below: the dataflow kernels win anyway (few launches' worth of rows)
 constexpr uint32_t kClusterDynamicPeriod = 8;  // cluster steps between two deals of the dynamic homes (a body that became active
                                                // since has none and is served as another cluster's body: slower, never wrong)
-// measured with tools/cluster_crossover.py (solve + rows, ms: cluster / dataflow): mixed piles 91k manifolds 0.518 / 0.450, 145k
-// 0.519 / 0.552, 155k 0.535 / 0.550; towers 92k 0.647 / 0.511, 182k 0.699 / 0.713, 256k 0.712 / 0.975 - the cluster kernel's
-// time is its chain (nearly the same at every size), the dataflow kernel's grows with the rows
-constexpr uint64_t kClusterMinManifolds = 131072;
+// measured with tools/cluster_crossover.py (solve + rows, ms: cluster / four-lane dataflow kernel with statically dealt items):
+// mixed piles 91k manifolds 0.518 / 0.353, 145k 0.519 / 0.486, 155k 0.535 / 0.494, 216k (C3) 0.576 / 0.696; towers 92k 0.647 /
+// 0.415, 182k 0.699 / 0.700, 256k 0.712 / 0.984 - the cluster kernel's time is its chain (nearly the same at every size), the
+// dataflow kernel's grows with the rows
+constexpr uint64_t kClusterMinManifolds = 170000;
 constexpr uint32_t kClusterMaxSlots = 2496;    // bodies per cluster whose {v, w, x, I^-1} fit one CU's LDS (64 B each: 156 KiB; 13-bit slot field)
 
 void set_error(const std::string& msg);

@@ -477,7 +477,7 @@ def test_frozen_scene_gives_the_same_manifolds_every_step_under_a_concurrent_gem
 def test_cluster_solver_bit_exact_against_the_oracle_on_a_33k_tower():
     """The cluster solver (cluster.hip: body velocities resident in LDS per spatial cluster, one launch for all
     iterations and colours, tagged granules only for bodies updated by another cluster's rows) takes over where contacts
-    are dense and plentiful (from 128k manifolds; asked for here with PHYS_FLAG_SOLVER_CLUSTER): a 16 x 130 x 16 tower of
+    are dense and plentiful (from 170k manifolds; asked for here with PHYS_FLAG_SOLVER_CLUSTER): a 16 x 130 x 16 tower of
     boxes in resting contact (33 280 bodies, ~100k manifolds). Same arithmetic, same order of updates per body as every
     other solver path: poses, velocities and counters equal the sequential CPU oracle's bit for bit."""
     import physics_amd
