@@ -67,6 +67,7 @@ void poll_snapshots(phys_world* w) {
         w->hint.valid = true;
         w->hint.n_manifolds = c.n_manifolds;
         w->hint.n_pairs = c.n_pairs;
+        w->hint.n_contacts = c.n_contacts;
         if (c.max_region) w->hint.max_region = c.max_region;
         w->hint.n_used_buckets = c.n_used_buckets;
         w->hint.n_colors = c.n_colors;

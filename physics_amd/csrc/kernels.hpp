@@ -1,6 +1,7 @@
 // kernels.hpp — shared includes and the host-side launch interface between the translation units
 // of libphysics_hip.so. Every launch_* enqueues on w->stream and returns without synchronising.
 #pragma once
+#include <algorithm>
 #include <hip/hip_runtime.h>
 
 #include "../../include/spec/collide.h"
@@ -188,6 +189,18 @@ int32_t halo_pairs(phys_world* w, const void* dev_remote, uint64_t n_remote, uin
 
 // cluster.hip
 int32_t cluster_assign(phys_world* w, const float* host_pos);
+// Which single-launch solver for a dense scene whose GPU is the world's alone (PHYS_FLAG_EXCLUSIVE_GPU: the dataflow kernel may
+// then fill the chip with three workgroups per CU, like the cluster kernel). Fitted to measurements of this build, ms per
+// sweep: the four-lane dataflow kernel at 672 workgroups 8.4e-8 M + 1.86e-8 K + 0.0009 C (C3 0.325 ms per solve, a 182k
+// tower 0.380, the 1M cubes in mid-fall 0.405, C5 1.07); the cluster kernel max(0.0041 C, 6.9e-8 M) + 10 % (C3 0.513, the
+// tower 0.636, the 1M cubes 0.235, C5 0.63): rows cost the dataflow kernel throughput, colours cost the cluster kernel
+// its chain. (Both give the same bits: the choice may change from update to update.)
+inline bool flow_quad_beats_cluster(uint32_t manifolds, uint32_t contacts, uint32_t colors) {
+    if (!colors || !contacts) return false;
+    const double flow = 8.4e-8 * manifolds + 1.86e-8 * contacts + 0.0009 * colors;
+    const double cluster = 1.1 * std::max(0.0041 * colors, 6.9e-8 * manifolds);
+    return flow < cluster;
+}
 void launch_cluster_sort(phys_world* w, unsigned blocks, StepCounters* snap_out /* host-mapped slot for the counters, or null */);
 #ifdef __HIPCC__
 // the step counters copied out to a host-mapped slot by the first workgroup of a kernel that runs after their last writer

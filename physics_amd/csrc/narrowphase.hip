@@ -874,6 +874,13 @@ void launch_coloring(phys_world* w) {
     w->cluster_step = (w->cluster_count > 0 || w->cluster_dynamic) && w->hint.valid && !small && dense &&
                       w->hint.n_manifolds >= cluster_min && !(w->cfg.flags & PHYS_FLAG_SOLVER_PER_COLOR) &&
                       w->cfg.solver_iterations > 0 && w->cfg.solver_iterations < 1000 && w->hint.n_colors > 0;
+    // ... unless the dataflow kernel is the faster one for this many rows and colours (kernels.hpp; only where it may take
+    // the whole chip: PHYS_FLAG_EXCLUSIVE_GPU, one world on the device)
+    static const bool no_flow_pref = getenv("PHYS_DEBUG_NO_FLOW_PREFERENCE") != nullptr;  // measurements; same bits
+    w->flow_wide = (w->cfg.flags & PHYS_FLAG_EXCLUSIVE_GPU) && !(w->cfg.flags & PHYS_FLAG_SHARED_GPU) && worlds_on_device(w->device) == 1;
+    if (w->cluster_step && !cluster_forced && !cluster_min_env && !no_flow_pref && w->flow_wide && w->hint.n_manifolds <= kFlowWideMaxManifolds &&
+        flow_quad_beats_cluster(w->hint.n_manifolds, w->hint.n_contacts, w->hint.n_colors))
+        w->cluster_step = false;
     if (w->cluster_step && w->cluster_dynamic) w->cluster_step = cluster_plan_dynamic(w);  // clusters and slots (every few updates)
     if (small) {
         // one workgroup does the whole stage, snapshot of the counters included
@@ -955,6 +962,7 @@ void launch_coloring(phys_world* w) {
             w->hint.valid = true;
             w->hint.n_manifolds = c.n_manifolds;
             w->hint.n_pairs = c.n_pairs;
+            w->hint.n_contacts = c.n_contacts;
             if (c.max_region) w->hint.max_region = c.max_region;
             w->hint.n_used_buckets = c.n_used_buckets;
             w->hint.n_colors = c.n_colors;

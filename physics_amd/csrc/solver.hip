@@ -1179,11 +1179,20 @@ void launch_solver(phys_world* w, float dt) {
         }
         // about one wave per SIMD or less: waiting waves must not crowd out the ones that can run
         static const uint64_t quad_max_env = getenv("PHYS_DEBUG_FLOW_QUAD_MAX") ? strtoull(getenv("PHYS_DEBUG_FLOW_QUAD_MAX"), nullptr, 10) : 0;  // measurements
-        const bool quad = m_hint <= (quad_max_env ? quad_max_env : kFlowQuadMaxManifolds);  // four lanes per manifold while the hop latency is everything
+        // four lanes per manifold while the hop latency is everything - and, where the launch may take the whole chip
+        // (w->flow_wide: three workgroups per CU, 672 of them), all the way up: 155k manifolds 0.250 ms against 0.446 with
+        // 224 workgroups, C3's 216k 0.325 (cluster kernel 0.513), the 1M cubes' 379k 0.405 (cluster kernel 0.235)
+        const bool quad = m_hint <= (quad_max_env ? quad_max_env : (w->flow_wide ? kFlowMaxManifolds : kFlowQuadMaxManifolds));
         const uint32_t threads = 256u;
         const uint32_t rows_per_item = quad ? threads / 4 : threads;
         uint64_t items = (uint64_t)sweeps * ((m_hint * 5 / 4 + rows_per_item - 1) / rows_per_item) + 1;
-        const uint64_t most = quad ? 224 : 256;
+        static const uint64_t wgs_env = getenv("PHYS_DEBUG_FLOW_WGS") ? strtoull(getenv("PHYS_DEBUG_FLOW_WGS"), nullptr, 10) : 0;  // measurements (quad)
+        int cus = 256;
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, w->device);
+        // statically dealt items need every workgroup running: a third of the chip's slots by default (beside other
+        // streams' kernels), seven eighths of them - the cluster kernel's share - where the GPU is this world's alone
+        // (small scenes are a chain of hand-offs, not throughput: C2's 10k manifolds 0.053 ms at 224 workgroups, 0.058 at 672)
+        const uint64_t most = quad ? (wgs_env ? wgs_env : (w->flow_wide && m_hint > 32768u ? (uint64_t)(3 * (cus - cus / 8)) : 224)) : 256;
         if (items > most) items = most;  // the remaining items are taken by the same workgroups
         PHYS_PROF(w, PHYS_STAGE_SOLVE_FLOW);
         // look one work item ahead (k_solve_flow) while a colour class keeps a good part of the launch busy; below that the

@@ -24,6 +24,7 @@ constexpr uint32_t kClusterDynamicPeriod = 8;  // cluster steps between two deal
 // 0.415, 182k 0.699 / 0.700, 256k 0.712 / 0.984 - the cluster kernel's time is its chain (nearly the same at every size), the
 // dataflow kernel's grows with the rows
 constexpr uint64_t kClusterMinManifolds = 170000;
+constexpr uint64_t kFlowWideMaxManifolds = 400000;  // the dataflow kernels' upper end (solver.hip kFlowMaxManifolds)
 constexpr uint32_t kClusterMaxSlots = 2496;    // bodies per cluster whose {v, w, x, I^-1} fit one CU's LDS (64 B each: 156 KiB; 13-bit slot field)
 
 void set_error(const std::string& msg);
@@ -157,7 +158,7 @@ struct ProfScope {
 // correctness
 struct StepHint {
     bool valid = false;
-    uint32_t n_manifolds = 0, n_colors = 0, n_pairs = 0, max_region = 0, n_used_buckets = 0;
+    uint32_t n_manifolds = 0, n_colors = 0, n_pairs = 0, max_region = 0, n_used_buckets = 0, n_contacts = 0;
     uint32_t n_active = 0;         // owned bodies with a manifold (0 = unknown)
     uint32_t color_rounds = 0;     // max over the recent INCREMENTAL updates
     uint32_t full_rounds = 0;      // rounds of the last full re-colouring (0 = unknown)
@@ -296,6 +297,7 @@ struct phys_world {
     phys::DevBuf<uint32_t> cluster_slot;   // body -> cluster * slots + slot
     phys::DevBuf<uint32_t> cluster_body;   // cluster * slots + slot -> body (0xFFFFFFFF: empty)
     phys::DevBuf<uint32_t> body_shared;    // 2 per body: 64-bit mask of the colours in which ANOTHER cluster's row updates it
+    bool flow_wide = false;          // this update: the four-lane dataflow kernel may use three workgroups per CU (exclusive GPU)
     bool seg_count_dirty = false;    // the (cluster, colour) counters were left non-zero by the last cluster step (three-launch scan)
     uint32_t seg_count_bins = 0;     // ... which used this many of them
     phys::DevBuf<uint32_t> seg_count, seg_start;  // rows per (cluster, colour) - kept behind body_shared, seg_count itself is unused - and their exclusive scan

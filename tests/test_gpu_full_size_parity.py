@@ -37,7 +37,7 @@ def _seeded_pair(sc, state, flags_extra=0):
     return w, o
 
 
-def _three_steps_side_by_side(sc, pre, min_manifolds, flags_extra=0):
+def _three_steps_side_by_side(sc, pre, min_manifolds, flags_extra=0, expect="cluster"):
     state, st0 = _advance_on_gpu(sc, pre)
     assert st0.overflow == 0 and st0.n_manifolds >= min_manifolds, (st0.n_manifolds, st0.overflow)
     w, o = _seeded_pair(sc, state, flags_extra)
@@ -53,8 +53,11 @@ def _three_steps_side_by_side(sc, pre, min_manifolds, flags_extra=0):
         for f in ("n_pairs", "n_manifolds", "n_contacts", "n_colors", "color_rounds"):
             assert getattr(sw, f) == getattr(so, f), (f, getattr(sw, f), getattr(so, f))
     prof, _ = w.profile_get()
-    # (two updates on the cluster solver; the default start is two enqueued attempts, the second returning at once)
-    assert "solve_cluster" in prof and prof["solve_cluster"][1] in (2, 4), f"cluster solver launches: {prof}"
+    if expect == "cluster":
+        # (two updates on the cluster solver; the default start is two enqueued attempts, the second returning at once)
+        assert "solve_cluster" in prof and prof["solve_cluster"][1] in (2, 4), f"cluster solver launches: {prof}"
+    else:
+        assert expect in prof and "solve_cluster" not in prof, f"expected {expect}: {prof}"
     n = w.get_stats().n_manifolds
     w.close()
     o.close()
@@ -80,6 +83,15 @@ def test_c3_100k_mixed_three_steps_equal_the_oracle():
     import physics_amd
     from physics_amd import scenes
     assert _three_steps_side_by_side(scenes.c3(), 155, 150_000, physics_amd.FLAG_SOLVER_CLUSTER) >= 150_000
+
+
+def test_c3_on_an_exclusive_gpu_takes_the_wide_dataflow_kernel_and_equals_the_oracle():
+    """C3 as the bench runs it (PHYS_FLAG_EXCLUSIVE_GPU): with 216k manifolds in 14 colours the four-lane dataflow kernel at
+    three workgroups per CU, its items dealt statically, is the faster single-launch solver (kernels.hpp
+    flow_quad_beats_cluster) - chosen over the cluster kernel from the second update on, same bits as the oracle."""
+    import physics_amd
+    from physics_amd import scenes
+    assert _three_steps_side_by_side(scenes.c3(), 155, 150_000, physics_amd.FLAG_EXCLUSIVE_GPU, expect="solve_flow") >= 150_000
 
 
 def test_c5_full_size_cluster_solver_equals_the_per_colour_kernels_over_40_steps():
