@@ -573,7 +573,7 @@ def main():
                        "solver_iterations": rig.iters, "dt_nanos": DT_NANOS, "preroll_steps": preroll,
                        "flags_note": "PHYS_FLAG_EXCLUSIVE_GPU: nothing else runs on the benchmark's GPU, so the cluster solver "
                                      "skips the all-or-nothing count of its workgroups (the default, for hosts that share the "
-                                     "GPU with a renderer: +0.04 ms per update on C5 and on the 1M cubes: tools/guard_cost.py)",
+                                     "GPU with a renderer: +0.04 ms per update on C5 and on the 1M cubes: tools/guard_cost.py), and the dataflow solver of mid-size scenes (C3) may use three workgroups per CU",
                        "timed_window": f"steps {preroll + args.warmup}..{preroll + args.warmup + args.steps} of the trajectory",
                        "sharding": "none" if not sharded else (
                            f"x-slabs x{n_gpus}, one process per GPU; " +

@@ -58,10 +58,12 @@ extern "C" {
                                             workgroups must all be resident - by default starts all-or-nothing (every
                                             workgroup is counted in before anything is written; a launch that does not
                                             fit beside other streams' kernels is called off and tried again: ~0.04
-                                            ms per update); with this flag it skips the count. A world that sets it on a
-                                            GPU that IS shared may spin into the solver's 3 s time-out (PHYS_ERR_HIP at
-                                            phys_sync). Several worlds of one process on a device are always guarded.
-                                            Same results either way. */
+                                            ms per update); with this flag it skips the count, and the dataflow solver of
+                                            mid-size scenes may fill the chip as well (three workgroups per CU instead of
+                                            a third of that: up to 1.8x faster at 100k-250k manifolds). A world that sets
+                                            it on a GPU that IS shared may spin into the solver's 3 s time-out
+                                            (PHYS_ERR_HIP at phys_sync). Several worlds of one process on a device are
+                                            always guarded. Same results either way. */
 #define PHYS_FLAG_SOLVER_CLUSTER 0x40u    /* contact solver: the cluster kernel (body velocities resident in LDS per spatial
                                             cluster, one launch) wherever the scene admits it (>= 32768 bodies, > 40k
                                             manifolds), instead of only where it is the fastest path (>= 170k manifolds).
