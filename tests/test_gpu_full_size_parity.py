@@ -89,8 +89,10 @@ def test_c3_on_an_exclusive_gpu_takes_the_wide_dataflow_kernel_and_equals_the_or
     """C3 as the bench runs it (PHYS_FLAG_EXCLUSIVE_GPU): with 216k manifolds in 14 colours the four-lane dataflow kernel at
     three workgroups per CU, its items dealt statically, is the faster single-launch solver (kernels.hpp
     flow_quad_beats_cluster) - chosen over the cluster kernel from the second update on, same bits as the oracle."""
+    import gc
     import physics_amd
     from physics_amd import scenes
+    gc.collect()  # the wide launch needs this world to be the only one on the device: none left over from earlier tests
     assert _three_steps_side_by_side(scenes.c3(), 155, 150_000, physics_amd.FLAG_EXCLUSIVE_GPU, expect="solve_flow") >= 150_000
 
 
